@@ -1,0 +1,268 @@
+/* pt_api.h — C-ABI boundary of the MI355X path-tracing hot path (libpathtracer_amd.so).
+ *
+ * The reference (domme/PathTracer) has no plugin/FFI API; the narrowest seam of its DXR path is
+ *   PathTracer::InitRtScene            PathTracer/PathTracer.cpp:171-339   (scene -> GPU buffers + BLAS/TLAS)
+ *   Sky::ComputeTranmittanceLut        PathTracer/Sky.cpp:127-148          (256x64 RGBA16F LUT)
+ *   PathTracer::RenderRT               PathTracer/PathTracer.cpp:659-787   (clear, RtConsts, DispatchRays)
+ *   PathTracer::RestartAccumulation    PathTracer/PathTracer.cpp:912-915
+ * Each entry point below names the piece of that seam it replaces. All functions return an int
+ * status (PT_OK == 0); nothing but plain pointers and sizes crosses the boundary; the caller owns
+ * every host array and the library copies what it keeps. One pt_ctx per device, driven by one host
+ * thread at a time (the reference is single render thread, PathTracer.cpp:576,591).
+ *
+ * Documented deviations from the reference:
+ *   Q1  sample position = uPixel + jitter, jitter in [0,1)^2, written to texel uPixel (race-free).
+ *   Q9  the RNG stream is keyed on (px, py, sampleIndex) with sampleIndex the 0-based accumulation
+ *       index (myFrameRandomSeed of the i-th sample of a pt_render call = first_sample + i).
+ *   The accumulation target holds the float SUM of samples (alpha 0) and the sample count; the mean
+ *   (the reference's running mean, PathTracing.hlsl:134-137) is formed on read.
+ */
+#ifndef PT_API_H
+#define PT_API_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- status codes (reference: ASSERT / IsValid(), PathTracer.cpp:102,105,108,273) ---- */
+enum {
+  PT_OK = 0,
+  PT_ERR_INVALID_ARG = 1,   /* null pointer, zero size, index out of range */
+  PT_ERR_NO_DEVICE = 2,     /* no HIP device / device index out of range */
+  PT_ERR_HIP = 3,           /* a HIP runtime call failed; see pt_last_error */
+  PT_ERR_NO_SCENE = 4,      /* render/trace before pt_scene_create */
+  PT_ERR_NO_TARGET = 5,     /* render/read before pt_accum_reset / pt_accum_bind */
+  PT_ERR_SIZE_MISMATCH = 6, /* w,h differ from the accumulation target */
+  PT_ERR_NO_SKY = 7,        /* mySampleSky != 0 before pt_sky_set */
+  PT_ERR_OUT_OF_MEMORY = 8,
+  PT_ERR_UNSUPPORTED = 9
+};
+
+typedef struct pt_ctx pt_ctx;
+
+/* ---- AtmosphereParameters: PathTracer/Sky.h:27-62 == resources/shaders/sky/Common.hlsl:7-43 (112 B) ---- */
+typedef struct PtAtmosphere {
+  float RayleighScattering[3];
+  float RayleighDensityExpScale;
+  float AbsorptionExtinction[3];
+  float BottomRadius;
+  float GroundAlbedo[3];
+  float TopRadius;
+  float MieScattering[3];
+  float MieDensityExpScale;
+  float MieExtinction[3];
+  float MiePhaseG;
+  float MieAbsorption[3];
+  float AbsorptionDensity0LayerWidth;
+  float AbsorptionDensity0ConstantTerm;
+  float AbsorptionDensity0LinearTerm;
+  float AbsorptionDensity1ConstantTerm;
+  float AbsorptionDensity1LinearTerm;
+} PtAtmosphere;
+
+/* ---- SkyConstants: PathTracer.cpp:689-707 == raytracing/Common.hlsl:10-22 (160 B) ---- */
+typedef struct PtSkyConstants {
+  PtAtmosphere myAtmosphere;
+  float mySunDirection[3];
+  uint32_t myTransmissionLutTexIdx; /* ignored: the LUT lives in the ctx */
+  float mySunIlluminance[3];
+  float _unused;
+  float myRayMarchMinMaxSPP[2];     /* reference always passes (4,14), PathTracer.cpp:707 */
+  float _unused2[2];
+} PtSkyConstants;
+
+/* ---- RtConsts: PathTracer.cpp:709-740 == raytracing/Common.hlsl:24-55 (288 B, bit-for-bit) ---- */
+typedef struct PtRtConsts {
+  float myNearPlaneCorner[3];
+  float myAoDistance;
+  float myXAxis[3];
+  uint32_t myOutTexIndex;               /* ignored (bindless index) */
+  float myYAxis[3];
+  uint32_t myAsIndex;                   /* ignored */
+  float myCameraPos[3];
+  uint32_t myInstanceDataBufferIndex;   /* ignored */
+  uint32_t myMaterialDataBufferIndex;   /* ignored */
+  uint32_t mySampleBufferIndex;         /* ignored (Halton buffer is never read by the shaders) */
+  uint32_t myFrameRandomSeed;           /* ignored by pt_render (Q9: seed = sample index); used by nothing else */
+  uint32_t myNumAccumulationFrames;     /* ignored: the ctx tracks the sample count */
+  uint32_t myLinearClampSamplerIndex;   /* ignored */
+  uint32_t myMaxRecursionDepth;         /* inclusive loop bound: depth d => up to d+1 rays (PathTracing.hlsl:68) */
+  uint32_t myLightInstanceId;
+  uint32_t myNumHaltonSamples;          /* ignored */
+  float myLightEmission[3];
+  uint32_t mySampleSky;
+  float mySkyFallbackEmission[3];
+  float myPhongSpecularPower;
+  PtSkyConstants mySkyConsts;
+} PtRtConsts;
+
+/* ---- scene description: the inputs of InitRtScene (PathTracer.cpp:171-339) ---- */
+/* One interleaved vertex = {pos f3, normal f3, uv f2}, 32-byte stride (LoadScene, PathTracer.cpp:116-120). */
+typedef struct PtVertex {
+  float pos[3];
+  float normal[3];
+  float uv[2];
+} PtVertex;
+
+typedef struct PtMeshDesc {
+  const PtVertex* vertices;   /* num_vertices entries */
+  uint32_t num_vertices;
+  const uint32_t* indices;    /* 3*num_triangles entries, R_32UI (PathTracer.cpp:204) */
+  uint32_t num_triangles;
+} PtMeshDesc;
+
+/* SceneMeshInstance (PathTracer.cpp:285-305): instance id == array index (:298). */
+typedef struct PtInstanceDesc {
+  uint32_t myMeshIndex;
+  uint32_t myMaterialIndex;
+  float myTransform[16];      /* column-major 4x4 (glm::float4x4), applied to positions */
+} PtInstanceDesc;
+
+/* MaterialData (PathTracer.cpp:318-329): {float3 emission; uint rgba8 colour, R in the low byte}. */
+typedef struct PtMaterial {
+  float myEmission[3];
+  uint32_t myColor;
+} PtMaterial;
+
+/* pt_scene_create flags */
+enum {
+  PT_SCENE_DEFAULT = 0,
+  /* The reference never transforms normals by the instance matrix (PathTracing.hlsl:24-27).
+     Set this to rotate them by the upper 3x3 of myTransform instead. */
+  PT_SCENE_TRANSFORM_NORMALS = 1
+};
+
+/* closest-hit record returned by the trace entry points */
+typedef struct PtHit {
+  float t;            /* RayTCurrent; < 0 on miss */
+  float u;            /* DXR barycentric .x  = weight of vertex 1 */
+  float v;            /* DXR barycentric .y  = weight of vertex 2 */
+  uint32_t prim;      /* global triangle id (instance-major order of pt_scene_create); 0xFFFFFFFF on miss */
+} PtHit;
+
+#define PT_MISS 0xFFFFFFFFu
+
+/* a ray for pt_trace_rays: RayDesc {Origin, TMin, Direction, TMax} (PathTracing.hlsl:57-61), 32 B */
+typedef struct PtRay {
+  float origin[3];
+  float tmin;
+  float dir[3];
+  float tmax;
+} PtRay;
+
+typedef struct PtStats {
+  uint64_t samples;        /* pixel-samples completed since the last pt_stats_reset */
+  uint64_t rays;           /* TraceRay-equivalents issued (primary included) */
+  uint64_t shaded_hits;    /* ClosestHit-equivalents */
+  uint64_t sky_misses;     /* SampleSkyLuminance calls */
+  uint64_t nodes_visited;  /* wide-BVH nodes fetched  (only when counting is on) */
+  uint64_t tris_tested;    /* triangles tested         (only when counting is on) */
+  uint64_t extend_launches;/* launches of the traversal (extend) kernel */
+  double extend_ms;        /* sum of their durations, HIP events on the ctx stream (only when timing is on) */
+  double render_ms;        /* sum of whole pt_render durations, HIP events (only when timing is on) */
+} PtStats;
+
+typedef struct PtSceneInfo {
+  uint32_t num_triangles;
+  uint32_t num_vertices;
+  uint32_t num_instances;
+  uint32_t num_materials;
+  uint32_t num_bvh_nodes;     /* 80-byte compressed 8-wide nodes */
+  uint32_t bvh_max_depth;
+  uint64_t bvh_bytes;         /* nodes + 48-byte triangle records */
+  float bounds_min[3];
+  float bounds_max[3];
+  double build_ms;
+} PtSceneInfo;
+
+/* options for pt_set_option */
+enum {
+  PT_OPT_COUNT_TRAVERSAL = 1, /* 0/1: run the counting instantiation of the extend kernel (fills nodes_visited/tris_tested) */
+  PT_OPT_TIME_KERNELS = 2,    /* 0/1: bracket kernels with HIP events (fills extend_ms/render_ms) */
+  PT_OPT_SAMPLES_PER_BATCH = 3, /* samples per pixel kept in flight per wavefront batch (0 = auto) */
+  PT_OPT_SKY_MODE = 4         /* 0 = ray-march on every miss (reference, SampleSky.hlsl:7-47); 1 = direction LUT (extension) */
+};
+
+/* ---- lifetime (replaces the RenderCore device + handle ownership, PathTracer.cpp:45-77,417-437) ---- */
+int pt_create(int device, pt_ctx** out_ctx);
+int pt_destroy(pt_ctx* ctx);
+/* Human-readable text for the last non-OK status on this ctx (never NULL). ctx may be NULL for create errors. */
+const char* pt_last_error(const pt_ctx* ctx);
+/* Run subsequent work on this hipStream_t (passed as void*); NULL = the ctx's own stream. */
+int pt_set_stream(pt_ctx* ctx, void* hip_stream);
+int pt_synchronize(pt_ctx* ctx);
+int pt_set_option(pt_ctx* ctx, int option, int64_t value);
+
+/* ---- scene: replaces PathTracer::InitRtScene incl. the driver BLAS/TLAS build (PathTracer.cpp:171-339) ----
+ * Flattens meshes x instances into world-space SoA triangle / vertex{normal,uv} / material buffers,
+ * builds a binned-SAH BVH collapsed to an 8-wide compressed BVH on the host and uploads everything.
+ * Instance flags are the reference's: cull disabled, forced opaque, mask 0xFF (PathTracer.cpp:302-304). */
+int pt_scene_create(pt_ctx* ctx,
+                    const PtMeshDesc* meshes, uint32_t num_meshes,
+                    const PtInstanceDesc* instances, uint32_t num_instances,
+                    const PtMaterial* materials, uint32_t num_materials,
+                    uint32_t flags);
+int pt_scene_info(const pt_ctx* ctx, PtSceneInfo* out);
+
+/* ---- sky: replaces Sky::ComputeTranmittanceLut + compute_transmittance_lut.hlsl (Sky.cpp:127-148) ----
+ * Recomputes the 256x64 RGBA16F transmittance LUT on the device for these atmosphere parameters. */
+int pt_sky_set(pt_ctx* ctx, const PtAtmosphere* atmosphere);
+/* Copy the LUT back: 256*64*4 binary16 values, row-major, RGBA. */
+int pt_sky_lut_read(pt_ctx* ctx, uint16_t* rgba16f);
+
+/* ---- accumulation target: replaces UpdateOutputTexture + RestartAccumulation + clear_texture.hlsl
+ *      (PathTracer.cpp:834-878, 912-915, 668-678) ---- */
+/* (Re)allocate a w x h RGBA32F target if the size changed, zero it, sample count = 0. */
+int pt_accum_reset(pt_ctx* ctx, uint32_t width, uint32_t height);
+/* Use caller-owned DEVICE memory (w*h*4 floats) as the target instead; zeroes it; count = 0.
+   Lets the host reduce it across GPUs (RCCL) without a copy. Pass NULL to return to an internal target. */
+int pt_accum_bind(pt_ctx* ctx, float* device_rgba, uint32_t width, uint32_t height);
+/* Device address + sample count of the current target (sum of samples, alpha 0). */
+int pt_accum_device_ptr(pt_ctx* ctx, float** device_rgba, uint64_t* num_samples);
+/* Overwrite the sample count (after an external reduce has summed other ranks' targets into this one). */
+int pt_accum_set_count(pt_ctx* ctx, uint64_t num_samples);
+/* Mean image = sum / count -> host, w*h*4 floats (what the reference's texture holds, PathTracing.hlsl:134-137). */
+int pt_accum_read(pt_ctx* ctx, float* host_rgba_mean);
+/* Raw sum -> host. */
+int pt_accum_read_sum(pt_ctx* ctx, float* host_rgba_sum, uint64_t* num_samples);
+
+/* ---- the hot path: replaces PathTracer::RenderRT + RayGen/ClosestHit/(miss) (PathTracer.cpp:659-787,
+ *      PathTracing.hlsl:16-138). Renders samples first_sample .. first_sample+num_samples-1 of every pixel
+ *      (one reference "frame" each) and adds them to the accumulation target. Asynchronous on the ctx stream. ---- */
+int pt_render(pt_ctx* ctx, const PtRtConsts* consts, uint32_t width, uint32_t height,
+              uint32_t first_sample, uint32_t num_samples);
+
+/* ---- parity / measurement helpers (no counterpart in the reference: TraceRay is a driver black box) ---- */
+/* Primary-ray closest hit per pixel for one sample index (RayGen lines 43-71 only). hits: w*h entries, host. */
+int pt_primary_hits(pt_ctx* ctx, const PtRtConsts* consts, uint32_t width, uint32_t height,
+                    uint32_t sample, PtHit* hits);
+/* Closest hit of arbitrary rays (TraceRay semantics: tmin < t < tmax, two-sided, opaque). Host arrays. */
+int pt_trace_rays(pt_ctx* ctx, const PtRay* rays, uint64_t num_rays, PtHit* hits);
+/* Same on DEVICE arrays already resident (used by the bench): no copies, asynchronous. */
+int pt_trace_rays_device(pt_ctx* ctx, const PtRay* device_rays, uint64_t num_rays, PtHit* device_hits);
+/* Evaluate one shading/sky device function on n rows of host inputs (see PT_FN_* for row layouts). */
+int pt_debug_eval(pt_ctx* ctx, int fn, const PtRtConsts* consts, const float* in, uint64_t n, float* out);
+int pt_stats_get(pt_ctx* ctx, PtStats* out);   /* synchronises the stream first */
+int pt_stats_reset(pt_ctx* ctx);
+
+/* function ids for pt_debug_eval: floats per input row -> floats per output row */
+enum {
+  PT_FN_RAND01 = 0,            /* in: px,py,seed,ndraws (as floats holding integers) -> out: 8 draws (first min(ndraws,8)) */
+  PT_FN_FRESNEL = 1,           /* in: N3,V3 (6)            -> out: 1   GetFresnelSchlick      Common.hlsl:196-201 */
+  PT_FN_SPEC_PROB = 2,         /* in: color3,fresnel (4)   -> out: 1   EstimateSpecularRayProbability brdfSampling.hlsl:41-49 */
+  PT_FN_SAMPLE_PHONG = 3,      /* in: u2,N3,power (6)      -> out: 4   dir3,pdf SampleModifiedPhong brdfSampling.hlsl:24-39 */
+  PT_FN_EVAL_PHONG = 4,        /* in: N3,L3,V3,power (10)  -> out: 1   EvaluateModifiedPhong(.,.,.,0.9,power) brdfSampling.hlsl:16-22 */
+  PT_FN_COS_HEMISPHERE = 5,    /* in: u2,N3 (5)            -> out: 3   GetCosineWeightedHemisphereDirection Common.hlsl:137-141 */
+  PT_FN_LAMBERT = 6,           /* in: color3,N3,L3 (9)     -> out: 4   brdf3,pdf brdfSampling.hlsl:6-14 */
+  PT_FN_SKY = 7,               /* in: viewPos3,viewDir3 (6)-> out: 3   SampleSkyLuminance SampleSky.hlsl:7-47 (uses consts + ctx LUT) */
+  PT_FN_PRIMARY_RAY = 8,       /* in: pixel2,res2 (4)      -> out: 6   origin3,dir3 GetPrimaryRay Common.hlsl:183-189 */
+  PT_FN_COUNT = 9
+};
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PT_API_H */

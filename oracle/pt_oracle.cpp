@@ -1,0 +1,374 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY.
+// Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library; the product
+// (pathtracer_amd/, libpathtracer_amd.so) never includes, links or calls anything under oracle/.
+//
+// What it is: a scalar C++ restatement of the reference's DXR path-tracing pipeline
+//   resources/shaders/raytracing/PathTracing.hlsl  (RayGen :40-138, ClosestHit :16-38)
+//   + Common.hlsl / Random.hlsl / brdfSampling.hlsl / SampleSky.hlsl / sky/Common.hlsl /
+//     sky/compute_transmittance_lut.hlsl, host side PathTracer/PathTracer.cpp:171-339,659-787, Sky.cpp:32-56,127-148
+// built with  g++ -O2 -ffp-contract=off -fopenmp  (oracle/Makefile).
+//
+// PINNING STATUS: the reference ships NO tests, golden vectors or fixtures for this path and cannot
+// be built or run here (Win32 + D3D12/DXR; FANCY engine submodule absent; no dxc). The only exact pins are the
+// integer KATs of pcg4d/GetRand01, derived by hand from Random.hlsl:45-62,84-99 and committed under tests/golden/.
+// Everything floating-point is therefore "PARITY UNPINNED" against a real DXR run: it is a careful transcription with
+// the adopted definitions listed in hlsl_math.h / sky.h / geometry.h, not a verified reproduction.
+//
+// Deviations from the literal HLSL, shared with the product:
+//   Q1  sample position = uPixel + jitter (jitter in [0,1)^2), written to texel uPixel. jitter_mode=1 switches to the
+//       literal reference behaviour (pixel += jitter-0.5, write to trunc(pixel)), race-free here because it runs serially.
+//   Q9  frame seed = 0-based sample (accumulation) index.
+#include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+#include "geometry.h"
+#include "shading.h"
+#include "sky.h"
+
+using namespace orc;
+
+static_assert(sizeof(PtRtConsts) == 288, "RtConsts must be 288 bytes (PathTracer.cpp:709-740)");
+static_assert(sizeof(PtSkyConstants) == 160, "SkyConstants must be 160 bytes");
+static_assert(offsetof(PtRtConsts, mySkyConsts) == 128, "SkyConstants offset");
+static_assert(offsetof(PtRtConsts, myLightEmission) == 96, "lightEmission offset");
+
+namespace {
+
+static inline float3 ld3(const float* p) { return f3(p[0], p[1], p[2]); }
+
+struct HitInfo {  // PathTracing.hlsl:7-14
+  float3 myHitPos, myHitNormal, myColor, myEmission;
+  bool myHasHit;
+};
+
+// ClosestHit — PathTracing.hlsl:16-38 (+ loaders Common.hlsl:75-127)
+static inline void ClosestHit(const Scene& S, const PtRtConsts& c, const PtHit& h, float3 rayOrigin, float3 rayDir,
+                              HitInfo& payload) {
+  uint32_t instanceId = S.tri_instance[h.prim];                       // InstanceID()
+  uint32_t materialIndex = S.instance_material[instanceId];           // LoadInstanceData
+  const PtMaterial& enc = S.materials[materialIndex];                 // LoadMaterialData
+  float3 matColor = Decode_Unorm_RGB(enc.myColor);
+  float3 matEmission = ld3(enc.myEmission);
+  // LoadInterpolatedVertexData — Common.hlsl:112-127. attrib.bary = DXR barycentrics (x: weight of vertex 1,
+  // y: weight of vertex 2) fed into the reference's formula unchanged. myUv is interpolated by the
+  // reference too but never read by the path-tracing pipeline.
+  const uint32_t* idx = &S.tri_indices[3 * (size_t)h.prim];
+  float3 n0 = S.vertex_normal[idx[0]], n1 = S.vertex_normal[idx[1]], n2 = S.vertex_normal[idx[2]];
+  float baryZ = 1.0f - (h.u + h.v);
+  float3 normal = h.u * n0 + h.v * n1 + baryZ * n2;
+  payload.myHasHit = true;
+  payload.myHitNormal = normal;
+  payload.myHitPos = rayOrigin + rayDir * h.t;
+  payload.myColor = matColor;
+  payload.myEmission = matEmission;
+  if (dot(payload.myHitNormal, -rayDir) < 0.0f) payload.myHitNormal = -payload.myHitNormal;
+  if (instanceId == c.myLightInstanceId) payload.myEmission = ld3(c.myLightEmission);
+}
+
+struct SampleStats { uint64_t rays = 0, hits = 0, sky = 0, nodes = 0, tris = 0; };
+
+// RayGen — PathTracing.hlsl:40-138, one sample of one pixel. Returns the (scrubbed) luminance and the texel to write.
+static inline float3 RayGenSample(const Scene& S, const PtRtConsts& c, const uint16_t* lut, uint32_t px, uint32_t py,
+                                  uint32_t resX, uint32_t resY, uint32_t frameSeed, int jitter_mode, int brute,
+                                  SampleStats& st, int& outX, int& outY, bool count_traversal) {
+  uint4 rngState = InitRNG(px, py, frameSeed);
+  float2 pixel = {(float)px, (float)py};
+  float jx = GetRand01(rngState);
+  float jy = GetRand01(rngState);
+  if (jitter_mode == 1) {  // literal: pixel += lerp(-0.5.xx, 0.5.xx, jitter)  (:50)
+    pixel.x += lerpf(-0.5f, 0.5f, jx);
+    pixel.y += lerpf(-0.5f, 0.5f, jy);
+  } else {                 // Q1 deviation
+    pixel.x += jx;
+    pixel.y += jy;
+  }
+  pixel.x = clampf(pixel.x, 0.0f, (float)resX);
+  pixel.y = clampf(pixel.y, 0.0f, (float)resY);
+
+  float3 origin, dir;
+  GetPrimaryRay(pixel, resX, resY, ld3(c.myNearPlaneCorner), ld3(c.myXAxis), ld3(c.myYAxis), ld3(c.myCameraPos), origin, dir);
+  float tmin = 0.0f;
+  const float tmax = 10000.0f;
+
+  float3 luminance = f3(0.0f);
+  float3 transmission = f3(1.0f);
+  HitInfo hitInfo;
+  TraceCounters tc;
+  for (uint32_t bounceIdx = 0u; bounceIdx <= c.myMaxRecursionDepth; ++bounceIdx) {
+    hitInfo.myHasHit = false;
+    st.rays++;
+    PtHit h = brute ? trace_brute(S, origin, tmin, dir, tmax) : trace_bvh(S, origin, tmin, dir, tmax, count_traversal ? &tc : nullptr);
+    if (h.prim != PT_MISS) ClosestHit(S, c, h, origin, dir, hitInfo);
+    if (!hitInfo.myHasHit) {
+      st.sky++;
+      luminance += transmission * SampleSkyLuminance(origin, dir, c, lut);
+      break;
+    }
+    st.hits++;
+    float specularStrength = 0.9f;
+    float specularPower = c.myPhongSpecularPower;
+    float fresnel = GetFresnelSchlick(hitInfo.myHitNormal, -dir);
+    float specRayProbability = EstimateSpecularRayProbability(specularStrength, hitInfo.myColor, fresnel);
+    if (GetRand01(rngState) < specRayProbability) {
+      float pdf;
+      float u0 = GetRand01(rngState);  // float2(GetRand01, GetRand01): evaluated left to right (adopted)
+      float u1 = GetRand01(rngState);
+      float3 nextSampleDir = SampleModifiedPhong(float2{u0, u1}, hitInfo.myHitNormal, specularPower, pdf);
+      float3 brdf = f3(fresnel * EvaluateModifiedPhong(hitInfo.myHitNormal, nextSampleDir, -dir, specularStrength, specularPower));
+      transmission *= brdf / hmax(0.01f, pdf);
+      transmission /= specRayProbability;
+      dir = nextSampleDir;
+    } else {
+      float3 brdf = (1.0f - fresnel) * GetLambertianBRDF(hitInfo.myColor, hitInfo.myHitNormal, -dir);
+      float pdf = GetLambertianPDF(hitInfo.myHitNormal, -dir);
+      transmission *= brdf / pdf;
+      transmission /= (1.0f - specRayProbability);
+      float u0 = GetRand01(rngState);
+      float u1 = GetRand01(rngState);
+      dir = GetCosineWeightedHemisphereDirection(float2{u0, u1}, hitInfo.myHitNormal);
+    }
+    luminance += transmission * hitInfo.myEmission;
+    origin = hitInfo.myHitPos;
+    tmin = 0.001f;
+  }
+  st.nodes += tc.nodes; st.tris += tc.tris;
+  if (std::isnan(luminance.x) || std::isnan(luminance.y) || std::isnan(luminance.z) || std::isinf(luminance.x) ||
+      std::isinf(luminance.y) || std::isinf(luminance.z))
+    luminance = f3(0.0f);
+  if (jitter_mode == 1) { outX = (int)pixel.x; outY = (int)pixel.y; }  // theRwTextures2D[..][pixel]: float index truncated
+  else { outX = (int)px; outY = (int)py; }
+  return luminance;
+}
+
+}  // namespace
+
+extern "C" {
+
+// ---- exact integer pins ----
+void orc_pcg4d(const uint32_t in[4], uint32_t out[4]) {
+  uint4 r = pcg4d(uint4{in[0], in[1], in[2], in[3]});
+  out[0] = r.x; out[1] = r.y; out[2] = r.z; out[3] = r.w;
+}
+void orc_rand01(uint32_t px, uint32_t py, uint32_t seed, uint32_t n, float* out) {
+  uint4 s = InitRNG(px, py, seed);
+  for (uint32_t i = 0; i < n; ++i) out[i] = GetRand01(s);
+}
+uint32_t orc_encode_unorm_rgba(const float c[4]) {
+  uint32_t r = 0;
+  for (int k = 0; k < 4; ++k) {
+    float v = clampf(c[k], 0.0f, 1.0f);
+    r |= (uint32_t)floorf(v * 255.0f + 0.5f) << (8 * k);
+  }
+  return r;
+}
+uint16_t orc_float_to_half(float f) { return float_to_half(f); }
+float orc_half_to_float(uint16_t h) { return half_to_float(h); }
+
+void orc_earth_atmosphere(PtAtmosphere* out) {
+  Atmosphere a;
+  SetupEarthAtmosphere(a);
+  memcpy(out, &a, sizeof(a));
+}
+
+// compute_transmittance_lut.hlsl over the whole 256x64 texture -> RGBA16F
+void orc_transmittance_lut(const PtAtmosphere* atm, uint16_t* out_rgba16f) {
+  Atmosphere A;
+  memcpy(&A, atm, sizeof(A));
+#pragma omp parallel for schedule(dynamic, 4)
+  for (int y = 0; y < TRANSMITTANCE_TEXTURE_HEIGHT; ++y)
+    for (int x = 0; x < TRANSMITTANCE_TEXTURE_WIDTH; ++x)
+      TransmittanceLutTexel(A, (uint32_t)x, (uint32_t)y, &out_rgba16f[((size_t)y * TRANSMITTANCE_TEXTURE_WIDTH + x) * 4]);
+}
+
+// Row layouts identical to pt_debug_eval (include/pt_api.h, PT_FN_*).
+int orc_eval(int fn, const PtRtConsts* c, const uint16_t* lut, const float* in, uint64_t n, float* out) {
+  for (uint64_t i = 0; i < n; ++i) {
+    switch (fn) {
+      case PT_FN_RAND01: {
+        const float* r = in + 4 * i;
+        uint4 s = InitRNG((uint32_t)r[0], (uint32_t)r[1], (uint32_t)r[2]);
+        uint32_t nd = (uint32_t)r[3];
+        for (uint32_t k = 0; k < 8; ++k) out[8 * i + k] = k < nd ? GetRand01(s) : 0.0f;
+      } break;
+      case PT_FN_FRESNEL: {
+        const float* r = in + 6 * i;
+        out[i] = GetFresnelSchlick(ld3(r), ld3(r + 3));
+      } break;
+      case PT_FN_SPEC_PROB: {
+        const float* r = in + 4 * i;
+        out[i] = EstimateSpecularRayProbability(0.9f, ld3(r), r[3]);
+      } break;
+      case PT_FN_SAMPLE_PHONG: {
+        const float* r = in + 6 * i;
+        float pdf;
+        float3 d = SampleModifiedPhong(float2{r[0], r[1]}, ld3(r + 2), r[5], pdf);
+        out[4 * i] = d.x; out[4 * i + 1] = d.y; out[4 * i + 2] = d.z; out[4 * i + 3] = pdf;
+      } break;
+      case PT_FN_EVAL_PHONG: {
+        const float* r = in + 10 * i;
+        out[i] = EvaluateModifiedPhong(ld3(r), ld3(r + 3), ld3(r + 6), 0.9f, r[9]);
+      } break;
+      case PT_FN_COS_HEMISPHERE: {
+        const float* r = in + 5 * i;
+        float3 d = GetCosineWeightedHemisphereDirection(float2{r[0], r[1]}, ld3(r + 2));
+        out[3 * i] = d.x; out[3 * i + 1] = d.y; out[3 * i + 2] = d.z;
+      } break;
+      case PT_FN_LAMBERT: {
+        const float* r = in + 9 * i;
+        float3 b = GetLambertianBRDF(ld3(r), ld3(r + 3), ld3(r + 6));
+        out[4 * i] = b.x; out[4 * i + 1] = b.y; out[4 * i + 2] = b.z; out[4 * i + 3] = GetLambertianPDF(ld3(r + 3), ld3(r + 6));
+      } break;
+      case PT_FN_SKY: {
+        const float* r = in + 6 * i;
+        float3 L = SampleSkyLuminance(ld3(r), ld3(r + 3), *c, lut);
+        out[3 * i] = L.x; out[3 * i + 1] = L.y; out[3 * i + 2] = L.z;
+      } break;
+      case PT_FN_PRIMARY_RAY: {
+        const float* r = in + 4 * i;
+        float3 o, d;
+        GetPrimaryRay(float2{r[0], r[1]}, (uint32_t)r[2], (uint32_t)r[3], ld3(c->myNearPlaneCorner), ld3(c->myXAxis),
+                      ld3(c->myYAxis), ld3(c->myCameraPos), o, d);
+        out[6 * i] = o.x; out[6 * i + 1] = o.y; out[6 * i + 2] = o.z; out[6 * i + 3] = d.x; out[6 * i + 4] = d.y; out[6 * i + 5] = d.z;
+      } break;
+      default: return 1;
+    }
+  }
+  return 0;
+}
+
+// ---- scene ----
+void* orc_scene_create(const PtMeshDesc* meshes, uint32_t nm, const PtInstanceDesc* inst, uint32_t ni,
+                       const PtMaterial* mats, uint32_t nmat, uint32_t flags) {
+  for (uint32_t i = 0; i < ni; ++i)
+    if (inst[i].myMeshIndex >= nm || inst[i].myMaterialIndex >= nmat) return nullptr;
+  Scene* S = new Scene();
+  flatten(*S, meshes, nm, inst, ni, mats, nmat, flags);
+  build_bvh2(*S);
+  return S;
+}
+void orc_scene_destroy(void* s) { delete (Scene*)s; }
+uint32_t orc_scene_num_triangles(void* s) { return (uint32_t)((Scene*)s)->tris.size(); }
+// world-space triangle i as 9 floats + its instance id (so tests can check the product's flattening)
+void orc_scene_triangle(void* s, uint32_t i, float out9[9], uint32_t* instance) {
+  const Scene* S = (const Scene*)s;
+  const Tri& t = S->tris[i];
+  const float v[9] = {t.v0.x, t.v0.y, t.v0.z, t.v1.x, t.v1.y, t.v1.z, t.v2.x, t.v2.y, t.v2.z};
+  memcpy(out9, v, sizeof(v));
+  *instance = S->tri_instance[i];
+}
+
+// TraceRay over explicit rays. brute!=0: all-triangles loop. counters (optional): [0]=BVH2 nodes, [1]=tris tested.
+void orc_trace_rays(void* s, const PtRay* rays, uint64_t n, PtHit* hits, int brute, uint64_t* counters) {
+  const Scene& S = *(const Scene*)s;
+  uint64_t cn = 0, ct = 0;
+#pragma omp parallel for schedule(dynamic, 256) reduction(+ : cn, ct)
+  for (int64_t i = 0; i < (int64_t)n; ++i) {
+    const PtRay& r = rays[i];
+    TraceCounters tc;
+    hits[i] = brute ? trace_brute(S, ld3(r.origin), r.tmin, ld3(r.dir), r.tmax)
+                    : trace_bvh(S, ld3(r.origin), r.tmin, ld3(r.dir), r.tmax, counters ? &tc : nullptr);
+    cn += tc.nodes; ct += tc.tris;
+  }
+  if (counters) { counters[0] = cn; counters[1] = ct; }
+}
+
+// RayGen lines 43-71 only: the primary ray of (pixel, sample) and its closest hit.
+void orc_primary_hits(void* s, const PtRtConsts* c, uint32_t w, uint32_t h, uint32_t sample, PtHit* hits, int brute,
+                      PtRay* rays_out /*optional*/) {
+  const Scene& S = *(const Scene*)s;
+#pragma omp parallel for schedule(dynamic, 4)
+  for (int y = 0; y < (int)h; ++y)
+    for (uint32_t x = 0; x < w; ++x) {
+      uint4 rng = InitRNG(x, (uint32_t)y, sample);
+      float jx = GetRand01(rng), jy = GetRand01(rng);
+      float2 pixel = {clampf((float)x + jx, 0.0f, (float)w), clampf((float)y + jy, 0.0f, (float)h)};
+      float3 o, d;
+      GetPrimaryRay(pixel, w, h, ld3(c->myNearPlaneCorner), ld3(c->myXAxis), ld3(c->myYAxis), ld3(c->myCameraPos), o, d);
+      size_t i = (size_t)y * w + x;
+      hits[i] = brute ? trace_brute(S, o, 0.0f, d, 10000.0f) : trace_bvh(S, o, 0.0f, d, 10000.0f);
+      if (rays_out) {
+        PtRay r = {{o.x, o.y, o.z}, 0.0f, {d.x, d.y, d.z}, 10000.0f};
+        rays_out[i] = r;
+      }
+    }
+}
+
+// Whole RenderRT equivalent on the CPU: samples [first_sample, first_sample+num_samples) of every pixel.
+//   accum_rgba : w*h*4 floats, in/out.
+//   accum_mode 0: accum += (L,0)  (sum; caller divides by the count — the product's target format)
+//   accum_mode 1: accum = (accum*N + (L,0)) / (N+1), N = n_prev + i  — the reference's literal running mean
+//                 (PathTracing.hlsl:134-137, myNumAccumulationFrames PathTracer.cpp:764)
+//   per_sample_rgb (optional): w*h*num_samples*3 floats, [sample][y][x][rgb] (jitter_mode 0 only)
+//   stats (optional, 8 x u64): rays, shaded hits, sky misses, samples, bvh2 nodes, tris tested, ns elapsed, threads
+void orc_render(void* s, const PtRtConsts* c, const uint16_t* lut, uint32_t w, uint32_t h, uint32_t first_sample,
+                uint32_t num_samples, float* accum_rgba, uint64_t n_prev, int accum_mode, int jitter_mode, int brute,
+                int count_traversal, uint64_t* stats, float* per_sample_rgb) {
+  const Scene& S = *(const Scene*)s;
+  uint64_t rays = 0, hits = 0, sky = 0, nodes = 0, tris = 0;
+  auto t0 = std::chrono::steady_clock::now();
+  for (uint32_t si = 0; si < num_samples; ++si) {  // one reference "frame" per sample index
+    const uint32_t seed = first_sample + si;
+    const float N = (float)(n_prev + si);
+    if (jitter_mode == 1) {
+      // literal reference indexing scatters to neighbouring texels: run serially (it is a data race on the GPU, Q1)
+      for (uint32_t y = 0; y < h; ++y)
+        for (uint32_t x = 0; x < w; ++x) {
+          SampleStats st; int ox, oy;
+          float3 L = RayGenSample(S, *c, lut, x, y, w, h, seed, 1, brute, st, ox, oy, count_traversal != 0);
+          rays += st.rays; hits += st.hits; sky += st.sky; nodes += st.nodes; tris += st.tris;
+          if (ox < 0 || oy < 0 || ox >= (int)w || oy >= (int)h) continue;  // out-of-bounds UAV write is dropped
+          float* a = &accum_rgba[((size_t)oy * w + ox) * 4];
+          const float Lv[4] = {L.x, L.y, L.z, 0.0f};
+          for (int k = 0; k < 4; ++k) a[k] = accum_mode == 1 ? (a[k] * N + Lv[k]) / (N + 1.0f) : a[k] + Lv[k];
+        }
+      continue;
+    }
+#pragma omp parallel for schedule(dynamic, 2) reduction(+ : rays, hits, sky, nodes, tris)
+    for (int y = 0; y < (int)h; ++y)
+      for (uint32_t x = 0; x < w; ++x) {
+        SampleStats st; int ox, oy;
+        float3 L = RayGenSample(S, *c, lut, x, (uint32_t)y, w, h, seed, 0, brute, st, ox, oy, count_traversal != 0);
+        rays += st.rays; hits += st.hits; sky += st.sky; nodes += st.nodes; tris += st.tris;
+        float* a = &accum_rgba[((size_t)y * w + x) * 4];
+        const float Lv[4] = {L.x, L.y, L.z, 0.0f};
+        for (int k = 0; k < 4; ++k) a[k] = accum_mode == 1 ? (a[k] * N + Lv[k]) / (N + 1.0f) : a[k] + Lv[k];
+        if (per_sample_rgb) {
+          float* p = &per_sample_rgb[(((size_t)si * h + y) * w + x) * 3];
+          p[0] = L.x; p[1] = L.y; p[2] = L.z;
+        }
+      }
+  }
+  auto t1 = std::chrono::steady_clock::now();
+  if (stats) {
+    stats[0] = rays; stats[1] = hits; stats[2] = sky; stats[3] = (uint64_t)w * h * num_samples;
+    stats[4] = nodes; stats[5] = tris;
+    stats[6] = (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(t1 - t0).count();
+#ifdef _OPENMP
+    stats[7] = (uint64_t)omp_get_max_threads();
+#else
+    stats[7] = 1;
+#endif
+  }
+}
+
+int orc_num_threads(void) {
+#ifdef _OPENMP
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}
+void orc_set_num_threads(int n) {
+#ifdef _OPENMP
+  omp_set_num_threads(n);
+#else
+  (void)n;
+#endif
+}
+
+}  // extern "C"

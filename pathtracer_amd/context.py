@@ -1,0 +1,179 @@
+"""Thin object wrapper over the C-ABI (include/pt_api.h): one Context == one pt_ctx == one GPU.
+
+Error behaviour mirrors the library: every call returns a status; non-zero raises PtError carrying pt_last_error.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import api
+
+
+class SceneData:
+    """What FANCY's MeshImporter hands to PathTracer::InitRtScene (PathTracer/PathTracer.cpp:115-132):
+    meshes = list of (vertices[VERTEX_DTYPE], indices[uint32, 3*T]); instances = list of
+    (mesh_index, material_index, 4x4 column-major transform or None); materials = list of
+    (emission rgb, colour rgba in [0,1])."""
+
+    def __init__(self, meshes, instances, materials, name=""):
+        self.meshes = [(np.ascontiguousarray(v, dtype=api.VERTEX_DTYPE), np.ascontiguousarray(i, dtype=np.uint32).reshape(-1))
+                       for v, i in meshes]
+        self.instances = [(int(m), int(mat), None if t is None else np.asarray(t, dtype=np.float32).reshape(16))
+                          for m, mat, t in instances]
+        self.materials = [(tuple(float(x) for x in e), tuple(float(x) for x in c)) for e, c in materials]
+        self.name = name
+
+    @property
+    def num_triangles(self):
+        return sum(len(self.meshes[m][1]) // 3 for m, _, _ in self.instances)
+
+
+def encode_unorm_rgba(c):
+    """MathUtil::Encode_Unorm_RGBA (FANCY, absent): round(clamp(c,0,1)*255), R in the low byte."""
+    out = 0
+    for k in range(4):
+        v = min(max(float(c[k]) if k < len(c) else 1.0, 0.0), 1.0)
+        out |= int(np.floor(np.float32(v) * np.float32(255.0) + np.float32(0.5))) << (8 * k)
+    return out
+
+
+def pack_scene(scene):
+    """SceneData -> (ctypes arrays, keepalive list) in the layout pt_scene_create / orc_scene_create take."""
+    keep = []
+    meshes = (api.PtMeshDesc * max(1, len(scene.meshes)))()
+    for i, (v, idx) in enumerate(scene.meshes):
+        keep += [v, idx]
+        meshes[i].vertices = v.ctypes.data
+        meshes[i].num_vertices = len(v)
+        meshes[i].indices = idx.ctypes.data
+        meshes[i].num_triangles = len(idx) // 3
+    inst = (api.PtInstanceDesc * max(1, len(scene.instances)))()
+    ident = np.eye(4, dtype=np.float32).reshape(16)
+    for i, (m, mat, t) in enumerate(scene.instances):
+        inst[i].myMeshIndex = m
+        inst[i].myMaterialIndex = mat
+        tt = ident if t is None else t
+        for k in range(16):
+            inst[i].myTransform[k] = float(tt[k])
+    mats = (api.PtMaterial * max(1, len(scene.materials)))()
+    for i, (e, c) in enumerate(scene.materials):
+        api.fill3(mats[i].myEmission, e)
+        mats[i].myColor = encode_unorm_rgba(c)
+    return meshes, len(scene.meshes), inst, len(scene.instances), mats, len(scene.materials), keep
+
+
+class Context:
+    def __init__(self, device=0):
+        self.lib = api.load_library()
+        h = C.c_void_p()
+        rc = self.lib.pt_create(int(device), C.byref(h))
+        if rc != api.PT_OK:
+            raise api.PtError(rc, self.lib.pt_last_error(None).decode())
+        self.h = h
+        self.device = int(device)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.pt_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc):
+        if rc != api.PT_OK:
+            raise api.PtError(rc, self.lib.pt_last_error(self.h).decode())
+
+    # ---- scene / sky ----
+    def scene_create(self, scene, flags=api.PT_SCENE_DEFAULT):
+        m, nm, i, ni, mt, nmt, keep = pack_scene(scene)
+        self._ck(self.lib.pt_scene_create(self.h, m, nm, i, ni, mt, nmt, flags))
+        del keep
+
+    def scene_info(self):
+        info = api.PtSceneInfo()
+        self._ck(self.lib.pt_scene_info(self.h, C.byref(info)))
+        return info
+
+    def sky_set(self, atmosphere):
+        self._ck(self.lib.pt_sky_set(self.h, C.byref(atmosphere)))
+
+    def sky_lut_read(self):
+        out = np.empty((api.TLUT_H, api.TLUT_W, 4), dtype=np.uint16)
+        self._ck(self.lib.pt_sky_lut_read(self.h, api.ptr(out)))
+        return out
+
+    # ---- accumulation ----
+    def accum_reset(self, w, h):
+        self._ck(self.lib.pt_accum_reset(self.h, w, h))
+        self.w, self.hgt = w, h
+
+    def accum_bind(self, device_ptr, w, h):
+        self._ck(self.lib.pt_accum_bind(self.h, C.c_void_p(device_ptr), w, h))
+        self.w, self.hgt = w, h
+
+    def accum_device_ptr(self):
+        p = C.c_void_p()
+        n = C.c_uint64()
+        self._ck(self.lib.pt_accum_device_ptr(self.h, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def accum_set_count(self, n):
+        self._ck(self.lib.pt_accum_set_count(self.h, int(n)))
+
+    def accum_read(self):
+        out = np.empty((self.hgt, self.w, 4), dtype=np.float32)
+        self._ck(self.lib.pt_accum_read(self.h, api.ptr(out)))
+        return out
+
+    def accum_read_sum(self):
+        out = np.empty((self.hgt, self.w, 4), dtype=np.float32)
+        n = C.c_uint64()
+        self._ck(self.lib.pt_accum_read_sum(self.h, api.ptr(out), C.byref(n)))
+        return out, n.value
+
+    # ---- hot path ----
+    def render(self, consts, w, h, first_sample, num_samples):
+        self._ck(self.lib.pt_render(self.h, C.byref(consts), w, h, first_sample, num_samples))
+
+    def primary_hits(self, consts, w, h, sample=0):
+        out = np.empty((h, w), dtype=api.HIT_DTYPE)
+        self._ck(self.lib.pt_primary_hits(self.h, C.byref(consts), w, h, sample, api.ptr(out)))
+        return out
+
+    def trace_rays(self, rays):
+        rays = np.ascontiguousarray(rays, dtype=api.RAY_DTYPE)
+        out = np.empty(len(rays), dtype=api.HIT_DTYPE)
+        self._ck(self.lib.pt_trace_rays(self.h, api.ptr(rays), len(rays), api.ptr(out)))
+        return out
+
+    def trace_rays_device(self, rays_ptr, n, hits_ptr):
+        self._ck(self.lib.pt_trace_rays_device(self.h, C.c_void_p(rays_ptr), int(n), C.c_void_p(hits_ptr)))
+
+    def debug_eval(self, fn, rows, consts=None):
+        rows = np.ascontiguousarray(rows, dtype=np.float32).reshape(-1, api.FN_IN_WIDTH[fn])
+        out = np.empty((len(rows), api.FN_OUT_WIDTH[fn]), dtype=np.float32)
+        cp = C.byref(consts) if consts is not None else None
+        self._ck(self.lib.pt_debug_eval(self.h, fn, cp, api.ptr(rows), len(rows), api.ptr(out)))
+        return out
+
+    # ---- misc ----
+    def set_option(self, opt, value):
+        self._ck(self.lib.pt_set_option(self.h, opt, int(value)))
+
+    def set_stream(self, stream_handle):
+        self._ck(self.lib.pt_set_stream(self.h, C.c_void_p(stream_handle)))
+
+    def synchronize(self):
+        self._ck(self.lib.pt_synchronize(self.h))
+
+    def stats(self):
+        s = api.PtStats()
+        self._ck(self.lib.pt_stats_get(self.h, C.byref(s)))
+        return s
+
+    def stats_reset(self):
+        self._ck(self.lib.pt_stats_reset(self.h))

@@ -1,0 +1,67 @@
+// kernels.h — host-callable launchers of the HIP kernels (kernels.hip). Internal to libpathtracer_amd.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/pt_api.h"
+
+namespace pt {
+
+// device-resident scene (all pointers are device memory)
+struct DeviceScene {
+  const uint4* nodes = nullptr;        // 5 x uint4 per 80-byte BVH8 node
+  const uint4* tris = nullptr;         // 3 x uint4 per 48-byte triangle record (leaf order)
+  const uint4* prim_data = nullptr;    // per global triangle id: i0,i1,i2 (global vertex ids), instance id
+  const float4* vertex_normal = nullptr;
+  const float2* vertex_uv = nullptr;
+  const uint32_t* instance_material = nullptr;
+  const float4* materials = nullptr;   // emission.xyz, rgba8 bits
+  uint32_t stack_entries = 0;          // LDS stack entries per lane needed by trace_closest
+};
+
+// device counter block (u32), zeroed at the start of every wavefront batch
+enum {
+  CTR_QCOUNT0 = 0,      // [0..63]   rays queued for bounce b
+  CTR_WORK0 = 64,       // [64..127] work-distribution cursor of the extend kernel for bounce b
+  CTR_SKY = 128,        // sky-queue length
+  CTR_SHADED = 129,     // ClosestHit-equivalents this batch
+  CTR_WORDS = 160
+};
+// persistent device statistics (u64)
+enum { ST_SAMPLES = 0, ST_RAYS, ST_SHADED, ST_SKY, ST_NODES, ST_TRIS, ST_WORDS = 8 };
+
+struct WavefrontBuffers {
+  float4* ray_o[2] = {nullptr, nullptr};  // origin.xyz, tmin
+  float4* ray_d[2] = {nullptr, nullptr};  // dir.xyz, tmax
+  uint32_t* qid[2] = {nullptr, nullptr};  // path id of queue slot
+  float4* hits = nullptr;                 // t,u,v,prim bits
+  float4* st_T = nullptr;                 // throughput.xyz, rng draw counter bits
+  float4* st_L = nullptr;                 // luminance.xyz, -
+  float4* sky_o = nullptr;                // ray origin.xyz, path id bits
+  float4* sky_d = nullptr;                // ray dir.xyz, -
+  uint32_t* counters = nullptr;           // CTR_WORDS
+  unsigned long long* stats = nullptr;    // ST_WORDS
+  uint64_t capacity = 0;                  // paths
+};
+
+struct LaunchCfg {
+  int num_cus = 256;
+  int extend_blocks = 1024;   // persistent grid of the extend kernel
+  int stream_blocks = 2048;   // grid cap of the grid-stride kernels
+};
+
+void launch_transmittance_lut(const PtAtmosphere& atm, uint2* lut, hipStream_t s);
+void launch_generate(const PtRtConsts& c, const WavefrontBuffers& wb, uint32_t w, uint32_t h, uint32_t first_sample,
+                     uint32_t samples_in_batch, hipStream_t s);
+void launch_extend(const DeviceScene& sc, const float4* ray_o, const float4* ray_d, uint32_t stride, float4* hits, const uint32_t* count,
+                   uint32_t* work_cursor, unsigned long long* stats, bool count_traversal, const LaunchCfg& cfg, hipStream_t s);
+void launch_shade(const PtRtConsts& c, const DeviceScene& sc, const WavefrontBuffers& wb, int bounce, uint32_t w, uint32_t h,
+                  uint32_t first_sample, uint64_t max_paths, const LaunchCfg& cfg, hipStream_t s);
+void launch_sky(const PtRtConsts& c, const uint2* lut, const WavefrontBuffers& wb, uint64_t max_paths, const LaunchCfg& cfg, hipStream_t s);
+void launch_resolve(const WavefrontBuffers& wb, float4* accum, uint32_t w, uint32_t h, uint32_t samples_in_batch, uint32_t num_bounces,
+                    hipStream_t s);
+void launch_set_count(uint32_t* counter, uint32_t value, hipStream_t s);
+void launch_debug_eval(int fn, const PtRtConsts& c, const uint2* lut, const float* in, uint64_t n, float* out, hipStream_t s);
+size_t extend_lds_bytes(uint32_t stack_entries);
+int extend_occupancy_blocks(uint32_t stack_entries);
+
+}  // namespace pt

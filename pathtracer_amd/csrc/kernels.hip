@@ -1,0 +1,398 @@
+// kernels.hip — the wavefront path tracer's HIP kernels for gfx950 (MI355X).
+//
+// One reference "frame" (DispatchRays(w,h,1) of RayGen, PathTracer/PathTracer.cpp:777-784, PathTracing.hlsl:40-138)
+// is re-expressed as a pipeline over a batch of w*h*k path samples kept resident in HBM:
+//   generate : InitRNG + jitter + GetPrimaryRay                      (PathTracing.hlsl:43-66)
+//   extend   : TraceRay -> closest hit                               (PathTracing.hlsl:71)        [dominant kernel]
+//   shade    : ClosestHit + BRDF sampling + throughput/emission      (PathTracing.hlsl:16-38,73-127), survivors are
+//              compacted into the next bounce's ray queue with wave-aggregated atomics; misses go to the sky queue
+//   sky      : SampleSkyLuminance for every queued miss              (PathTracing.hlsl:75, SampleSky.hlsl:7-47)
+//   resolve  : NaN/Inf scrub + accumulation in sample order          (PathTracing.hlsl:130-137)
+// No kernel needs a host round trip: queue lengths live in device counters and the extend/shade/sky kernels are
+// persistent / grid-stride loops over them.
+#include "kernels.h"
+
+#include "shading_device.h"
+#include "sky_device.h"
+#include "traverse_device.h"
+
+namespace pt {
+using namespace ptd;
+
+static_assert(sizeof(PtRtConsts) == 288, "RtConsts is 288 bytes (PathTracer.cpp:709-740)");
+
+// ------------------------------------------------------------------------------------------------ helpers
+__device__ __forceinline__ uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+
+// Wave-aggregated queue append: one atomic per wave. Must be called by all 64 lanes convergently.
+__device__ __forceinline__ uint32_t wave_append(uint32_t* counter, bool pred) {
+  const unsigned long long mask = __ballot(pred);
+  const uint32_t lane = lane_id();
+  const uint32_t prefix = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+  uint32_t base = 0u;
+  if (mask != 0ull) {
+    const int leader = __ffsll((long long)mask) - 1;
+    if ((int)lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(mask));
+    base = (uint32_t)__shfl((int)base, leader);
+  }
+  return base + prefix;
+}
+
+// ------------------------------------------------------------------------------------------------ transmittance LUT
+// compute_transmittance_lut.hlsl main, [numthreads(8,8,1)] over 256x64 (Sky.cpp:145)
+__global__ void __launch_bounds__(256) k_transmittance_lut(PtAtmosphere atm, uint2* __restrict__ lut) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= PT_TLUT_W * PT_TLUT_H) return;
+  Atmo A;
+  __builtin_memcpy(&A, &atm, sizeof(A));
+  lut[i] = TransmittanceLutTexel(A, i % PT_TLUT_W, i / PT_TLUT_W);
+}
+
+// ------------------------------------------------------------------------------------------------ generate
+__global__ void __launch_bounds__(256) k_generate(PtRtConsts c, float4* __restrict__ ray_o, float4* __restrict__ ray_d,
+                                                  float4* __restrict__ st_T, float4* __restrict__ st_L,
+                                                  uint32_t* __restrict__ counters, uint32_t w, uint32_t h,
+                                                  uint32_t first_sample, uint32_t n_paths) {
+  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p == 0) counters[CTR_QCOUNT0] = n_paths;
+  if (p >= n_paths) return;
+  const uint32_t wh = w * h;
+  const uint32_t pix = p % wh, si = p / wh;
+  const uint32_t px = pix % w, py = pix / w;
+  Rng rng = InitRNG(px, py, first_sample + si);
+  // PathTracing.hlsl:47-51 with the Q1 deviation: position = uPixel + jitter, jitter in [0,1)^2
+  v2 pixel;
+  pixel.x = (float)px;
+  pixel.y = (float)py;
+  const float jx = GetRand01(rng);
+  const float jy = GetRand01(rng);
+  pixel.x += jx;
+  pixel.y += jy;
+  pixel.x = clampf(pixel.x, 0.0f, (float)w);
+  pixel.y = clampf(pixel.y, 0.0f, (float)h);
+  v3 o, d;
+  GetPrimaryRay(pixel, w, h, ld3(c.myNearPlaneCorner), ld3(c.myXAxis), ld3(c.myYAxis), ld3(c.myCameraPos), o, d);
+  ray_o[p] = make_float4(o.x, o.y, o.z, 0.0f);       // TMin 0.0   (:59)
+  ray_d[p] = make_float4(d.x, d.y, d.z, 10000.0f);   // TMax 10000 (:61)
+  st_T[p] = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(rng.w));
+  st_L[p] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+}
+
+// ------------------------------------------------------------------------------------------------ extend
+// Persistent waves: each wave claims 64 consecutive queue slots with one atomic, traces them, repeats.
+template <bool COUNT>
+__global__ void __launch_bounds__(256) k_extend(const uint4* __restrict__ nodes, const uint4* __restrict__ tris,
+                                                const float4* __restrict__ ray_o, const float4* __restrict__ ray_d,
+                                                float4* __restrict__ hits, const uint32_t* __restrict__ count_ptr,
+                                                uint32_t* __restrict__ work_cursor, unsigned long long* __restrict__ stats,
+                                                uint32_t stack_entries, uint32_t stride) {
+  extern __shared__ uint2 s_stack[];
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  uint2* stk = s_stack + (size_t)wave * stack_entries * 64u + lane;
+  const uint32_t n = *count_ptr;
+  uint32_t n_nodes = 0u, n_tris = 0u;
+  for (;;) {
+    uint32_t base = 0u;
+    if (lane == 0u) base = atomicAdd(work_cursor, 64u);
+    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+    if (base >= n) break;
+    const uint32_t i = base + lane;
+    if (i < n) {
+      const float4 ro = ray_o[(size_t)i * stride], rd = ray_d[(size_t)i * stride];
+      TraceRay r;
+      r.ox = ro.x; r.oy = ro.y; r.oz = ro.z; r.tmin = ro.w;
+      r.dx = rd.x; r.dy = rd.y; r.dz = rd.z; r.tmax = rd.w;
+      const HitRec hr = trace_closest<COUNT>(nodes, tris, r, stk, n_nodes, n_tris);
+      hits[i] = make_float4(hr.t, hr.u, hr.v, __uint_as_float(hr.prim));
+    }
+  }
+  if (COUNT) {
+    atomicAdd(&stats[ST_NODES], (unsigned long long)n_nodes);
+    atomicAdd(&stats[ST_TRIS], (unsigned long long)n_tris);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ shade
+__global__ void __launch_bounds__(256) k_shade(PtRtConsts c, DeviceScene sc, const float4* __restrict__ ray_o_in,
+                                               const float4* __restrict__ ray_d_in, const uint32_t* __restrict__ qid_in,
+                                               const float4* __restrict__ hits, float4* __restrict__ st_T,
+                                               float4* __restrict__ st_L, float4* __restrict__ ray_o_out,
+                                               float4* __restrict__ ray_d_out, uint32_t* __restrict__ qid_out,
+                                               float4* __restrict__ sky_o, float4* __restrict__ sky_d,
+                                               uint32_t* __restrict__ counters, int bounce, uint32_t w, uint32_t h,
+                                               uint32_t first_sample) {
+  const uint32_t n = counters[CTR_QCOUNT0 + bounce];
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wave_global = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const uint32_t waves_total = (gridDim.x * blockDim.x) >> 6;
+  const bool last_bounce = (uint32_t)bounce >= c.myMaxRecursionDepth;
+  const uint32_t wh = w * h;
+  uint32_t shaded_local = 0u;
+  for (uint32_t j0 = wave_global * 64u; j0 < n; j0 += waves_total * 64u) {  // wave-uniform trip count
+    const uint32_t j = j0 + lane;
+    const bool active = j < n;
+    bool want_ray = false, want_sky = false;
+    uint32_t pid = 0u;
+    v3 origin = mk3(0.0f), dir = mk3(0.0f), newOrigin = mk3(0.0f), newDir = mk3(0.0f);
+    if (active) {
+      pid = qid_in ? qid_in[j] : j;
+      const float4 ro = ray_o_in[j], rd = ray_d_in[j], hr = hits[j];
+      origin = mk3(ro.x, ro.y, ro.z);
+      dir = mk3(rd.x, rd.y, rd.z);
+      const uint32_t prim = __float_as_uint(hr.w);
+      if (prim == 0xFFFFFFFFu) {
+        // miss: PathTracing.hlsl:73-77
+        if (c.mySampleSky) {
+          want_sky = true;
+        } else {
+          const float4 T = st_T[pid];
+          float4 L = st_L[pid];
+          const v3 add = mk3(T.x, T.y, T.z) * ld3(c.mySkyFallbackEmission);
+          L.x += add.x; L.y += add.y; L.z += add.z;
+          st_L[pid] = L;
+        }
+      } else {
+        ++shaded_local;
+        // ---- ClosestHit: PathTracing.hlsl:16-38, loaders Common.hlsl:75-127 ----
+        const uint4 pd = sc.prim_data[prim];                 // LoadTriangleIndices + InstanceID()
+        const uint32_t instanceId = pd.w;
+        const uint32_t materialIndex = sc.instance_material[instanceId];   // LoadInstanceData
+        const float4 mat = sc.materials[materialIndex];      // LoadMaterialData
+        const float4 n0 = sc.vertex_normal[pd.x], n1 = sc.vertex_normal[pd.y], n2 = sc.vertex_normal[pd.z];
+        const float bu = hr.y, bv = hr.z;                    // attrib.bary (DXR meaning, Q5)
+        const float baryZ = 1.0f - (bu + bv);
+        v3 hitNormal = bu * mk3(n0.x, n0.y, n0.z) + bv * mk3(n1.x, n1.y, n1.z) + baryZ * mk3(n2.x, n2.y, n2.z);
+        const v3 hitPos = origin + dir * hr.x;
+        const v3 color = DecodeUnormRGB(__float_as_uint(mat.w));
+        v3 emission = mk3(mat.x, mat.y, mat.z);
+        if (dot(hitNormal, -dir) < 0.0f) hitNormal = -hitNormal;
+        if (instanceId == c.myLightInstanceId) emission = ld3(c.myLightEmission);
+
+        // ---- RayGen loop body: PathTracing.hlsl:83-127 ----
+        float4 Ts = st_T[pid];
+        float4 Ls = st_L[pid];
+        v3 transmission = mk3(Ts.x, Ts.y, Ts.z);
+        Rng rng;
+        const uint32_t pix = pid % wh;
+        rng.x = pix % w; rng.y = pix / w; rng.z = first_sample + pid / wh; rng.w = __float_as_uint(Ts.w);
+        const float specularStrength = 0.9f;
+        const float specularPower = c.myPhongSpecularPower;
+        const v3 V = -dir;
+        const float fresnel = GetFresnelSchlick(hitNormal, V);
+        const float specRayProbability = EstimateSpecularRayProbability(specularStrength, color, fresnel);
+        if (GetRand01(rng) < specRayProbability) {
+          float pdf;
+          v2 u;
+          u.x = GetRand01(rng);
+          u.y = GetRand01(rng);
+          const v3 nextSampleDir = SampleModifiedPhong(u, hitNormal, specularPower, pdf);
+          const v3 brdf = mk3(fresnel * EvaluateModifiedPhong(hitNormal, nextSampleDir, V, specularStrength, specularPower));
+          transmission = transmission * (brdf / fmaxf(0.01f, pdf));
+          transmission = transmission / specRayProbability;
+          newDir = nextSampleDir;
+        } else {
+          const v3 brdf = (1.0f - fresnel) * GetLambertianBRDF(color, hitNormal, V);
+          const float pdf = GetLambertianPDF(hitNormal, V);
+          transmission = transmission * (brdf / pdf);
+          transmission = transmission / (1.0f - specRayProbability);
+          v2 u;
+          u.x = GetRand01(rng);
+          u.y = GetRand01(rng);
+          newDir = GetCosineWeightedHemisphereDirection(u, hitNormal);
+        }
+        const v3 add = transmission * emission;   // :108 — after the throughput update (Q3)
+        Ls.x += add.x; Ls.y += add.y; Ls.z += add.z;
+        st_L[pid] = Ls;
+        if (!last_bounce) {
+          st_T[pid] = make_float4(transmission.x, transmission.y, transmission.z, __uint_as_float(rng.w));
+          newOrigin = hitPos;   // :126
+          want_ray = true;
+        }
+      }
+    }
+    // compaction (all 64 lanes take part)
+    const uint32_t slot = wave_append(&counters[CTR_QCOUNT0 + bounce + 1], want_ray);
+    if (want_ray) {
+      ray_o_out[slot] = make_float4(newOrigin.x, newOrigin.y, newOrigin.z, 0.001f);  // TMin 0.001 (:127)
+      ray_d_out[slot] = make_float4(newDir.x, newDir.y, newDir.z, 10000.0f);
+      qid_out[slot] = pid;
+    }
+    const uint32_t sslot = wave_append(&counters[CTR_SKY], want_sky);
+    if (want_sky) {
+      sky_o[sslot] = make_float4(origin.x, origin.y, origin.z, __uint_as_float(pid));
+      sky_d[sslot] = make_float4(dir.x, dir.y, dir.z, 0.0f);
+    }
+  }
+  // one atomic per wave for the statistics
+  for (int off = 32; off > 0; off >>= 1) shaded_local += (uint32_t)__shfl_down((int)shaded_local, off);
+  if (lane == 0u && shaded_local) atomicAdd(&counters[CTR_SHADED], shaded_local);
+}
+
+// ------------------------------------------------------------------------------------------------ sky
+__global__ void __launch_bounds__(256) k_sky(PtRtConsts c, const uint2* __restrict__ lut, const float4* __restrict__ sky_o,
+                                             const float4* __restrict__ sky_d, const float4* __restrict__ st_T,
+                                             float4* __restrict__ st_L, const uint32_t* __restrict__ counters) {
+  const uint32_t n = counters[CTR_SKY];
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const float4 o = sky_o[i], d = sky_d[i];
+    const uint32_t pid = __float_as_uint(o.w);
+    const v3 sky = SampleSkyLuminance(mk3(o.x, o.y, o.z), mk3(d.x, d.y, d.z), c, lut);
+    const float4 T = st_T[pid];
+    float4 L = st_L[pid];
+    const v3 add = mk3(T.x, T.y, T.z) * sky;
+    L.x += add.x; L.y += add.y; L.z += add.z;
+    st_L[pid] = L;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ resolve
+// PathTracing.hlsl:130-137 per sample, in sample-index order; the target keeps the SUM (pt_api.h header).
+__global__ void __launch_bounds__(256) k_resolve(const float4* __restrict__ st_L, float4* __restrict__ accum, uint32_t wh,
+                                                 uint32_t samples, uint32_t* __restrict__ counters,
+                                                 unsigned long long* __restrict__ stats, uint32_t num_bounces) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0) {
+    unsigned long long rays = 0ull;
+    for (uint32_t b = 0; b < num_bounces; ++b) rays += counters[CTR_QCOUNT0 + b];
+    stats[ST_RAYS] += rays;
+    stats[ST_SHADED] += counters[CTR_SHADED];
+    stats[ST_SKY] += counters[CTR_SKY];
+    stats[ST_SAMPLES] += (unsigned long long)wh * samples;
+  }
+  if (i >= wh) return;
+  float4 a = accum[i];
+  for (uint32_t s = 0; s < samples; ++s) {
+    float4 L = st_L[(size_t)s * wh + i];
+    if (isnan(L.x) || isnan(L.y) || isnan(L.z) || isinf(L.x) || isinf(L.y) || isinf(L.z)) { L.x = 0.0f; L.y = 0.0f; L.z = 0.0f; }
+    a.x += L.x; a.y += L.y; a.z += L.z;
+  }
+  accum[i] = a;
+}
+
+__global__ void k_set_count(uint32_t* counter, uint32_t value) { *counter = value; }
+
+// ------------------------------------------------------------------------------------------------ debug eval
+__global__ void __launch_bounds__(256) k_debug_eval(int fn, PtRtConsts c, const uint2* __restrict__ lut,
+                                                    const float* __restrict__ in, uint64_t n, float* __restrict__ out) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  switch (fn) {
+    case PT_FN_RAND01: {
+      const float* r = in + 4 * i;
+      Rng s = InitRNG((uint32_t)r[0], (uint32_t)r[1], (uint32_t)r[2]);
+      const uint32_t nd = (uint32_t)r[3];
+      for (uint32_t k = 0; k < 8; ++k) out[8 * i + k] = k < nd ? GetRand01(s) : 0.0f;
+    } break;
+    case PT_FN_FRESNEL: {
+      const float* r = in + 6 * i;
+      out[i] = GetFresnelSchlick(ld3(r), ld3(r + 3));
+    } break;
+    case PT_FN_SPEC_PROB: {
+      const float* r = in + 4 * i;
+      out[i] = EstimateSpecularRayProbability(0.9f, ld3(r), r[3]);
+    } break;
+    case PT_FN_SAMPLE_PHONG: {
+      const float* r = in + 6 * i;
+      float pdf;
+      v2 u; u.x = r[0]; u.y = r[1];
+      const v3 d = SampleModifiedPhong(u, ld3(r + 2), r[5], pdf);
+      out[4 * i] = d.x; out[4 * i + 1] = d.y; out[4 * i + 2] = d.z; out[4 * i + 3] = pdf;
+    } break;
+    case PT_FN_EVAL_PHONG: {
+      const float* r = in + 10 * i;
+      out[i] = EvaluateModifiedPhong(ld3(r), ld3(r + 3), ld3(r + 6), 0.9f, r[9]);
+    } break;
+    case PT_FN_COS_HEMISPHERE: {
+      const float* r = in + 5 * i;
+      v2 u; u.x = r[0]; u.y = r[1];
+      const v3 d = GetCosineWeightedHemisphereDirection(u, ld3(r + 2));
+      out[3 * i] = d.x; out[3 * i + 1] = d.y; out[3 * i + 2] = d.z;
+    } break;
+    case PT_FN_LAMBERT: {
+      const float* r = in + 9 * i;
+      const v3 b = GetLambertianBRDF(ld3(r), ld3(r + 3), ld3(r + 6));
+      out[4 * i] = b.x; out[4 * i + 1] = b.y; out[4 * i + 2] = b.z; out[4 * i + 3] = GetLambertianPDF(ld3(r + 3), ld3(r + 6));
+    } break;
+    case PT_FN_SKY: {
+      const float* r = in + 6 * i;
+      const v3 L = SampleSkyLuminance(ld3(r), ld3(r + 3), c, lut);
+      out[3 * i] = L.x; out[3 * i + 1] = L.y; out[3 * i + 2] = L.z;
+    } break;
+    case PT_FN_PRIMARY_RAY: {
+      const float* r = in + 4 * i;
+      v2 px; px.x = r[0]; px.y = r[1];
+      v3 o, d;
+      GetPrimaryRay(px, (uint32_t)r[2], (uint32_t)r[3], ld3(c.myNearPlaneCorner), ld3(c.myXAxis), ld3(c.myYAxis), ld3(c.myCameraPos), o, d);
+      out[6 * i] = o.x; out[6 * i + 1] = o.y; out[6 * i + 2] = o.z; out[6 * i + 3] = d.x; out[6 * i + 4] = d.y; out[6 * i + 5] = d.z;
+    } break;
+    default: break;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ launchers
+static inline int grid_for(uint64_t n, int cap) {
+  uint64_t g = (n + 255) / 256;
+  if (g < 1) g = 1;
+  if (cap > 0 && g > (uint64_t)cap) g = (uint64_t)cap;
+  return (int)g;
+}
+
+void launch_transmittance_lut(const PtAtmosphere& atm, uint2* lut, hipStream_t s) {
+  hipLaunchKernelGGL(k_transmittance_lut, dim3(PT_TLUT_W * PT_TLUT_H / 256), dim3(256), 0, s, atm, lut);
+}
+
+void launch_generate(const PtRtConsts& c, const WavefrontBuffers& wb, uint32_t w, uint32_t h, uint32_t first_sample,
+                     uint32_t samples_in_batch, hipStream_t s) {
+  const uint32_t n = w * h * samples_in_batch;
+  hipLaunchKernelGGL(k_generate, dim3(grid_for(n, 0)), dim3(256), 0, s, c, wb.ray_o[0], wb.ray_d[0], wb.st_T, wb.st_L,
+                     wb.counters, w, h, first_sample, n);
+}
+
+size_t extend_lds_bytes(uint32_t stack_entries) { return (size_t)stack_entries * 64u * sizeof(uint2) * 4u; }
+
+int extend_occupancy_blocks(uint32_t stack_entries) {
+  int nb = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_extend<false>, 256, extend_lds_bytes(stack_entries)) != hipSuccess || nb < 1) nb = 1;
+  return nb;
+}
+
+void launch_extend(const DeviceScene& sc, const float4* ray_o, const float4* ray_d, uint32_t stride, float4* hits, const uint32_t* count,
+                   uint32_t* work_cursor, unsigned long long* stats, bool count_traversal, const LaunchCfg& cfg, hipStream_t s) {
+  const size_t lds = extend_lds_bytes(sc.stack_entries);
+  if (count_traversal)
+    hipLaunchKernelGGL(k_extend<true>, dim3(cfg.extend_blocks), dim3(256), lds, s, sc.nodes, sc.tris, ray_o, ray_d, hits, count,
+                       work_cursor, stats, sc.stack_entries, stride);
+  else
+    hipLaunchKernelGGL(k_extend<false>, dim3(cfg.extend_blocks), dim3(256), lds, s, sc.nodes, sc.tris, ray_o, ray_d, hits, count,
+                       work_cursor, stats, sc.stack_entries, stride);
+}
+
+void launch_shade(const PtRtConsts& c, const DeviceScene& sc, const WavefrontBuffers& wb, int bounce, uint32_t w, uint32_t h,
+                  uint32_t first_sample, uint64_t max_paths, const LaunchCfg& cfg, hipStream_t s) {
+  const int in = bounce & 1, out = in ^ 1;
+  hipLaunchKernelGGL(k_shade, dim3(grid_for(max_paths, cfg.stream_blocks)), dim3(256), 0, s, c, sc, wb.ray_o[in], wb.ray_d[in],
+                     bounce == 0 ? (const uint32_t*)nullptr : wb.qid[in], wb.hits, wb.st_T, wb.st_L, wb.ray_o[out], wb.ray_d[out],
+                     wb.qid[out], wb.sky_o, wb.sky_d, wb.counters, bounce, w, h, first_sample);
+}
+
+void launch_sky(const PtRtConsts& c, const uint2* lut, const WavefrontBuffers& wb, uint64_t max_paths, const LaunchCfg& cfg, hipStream_t s) {
+  hipLaunchKernelGGL(k_sky, dim3(grid_for(max_paths, cfg.stream_blocks)), dim3(256), 0, s, c, lut, wb.sky_o, wb.sky_d, wb.st_T, wb.st_L,
+                     wb.counters);
+}
+
+void launch_resolve(const WavefrontBuffers& wb, float4* accum, uint32_t w, uint32_t h, uint32_t samples_in_batch, uint32_t num_bounces,
+                    hipStream_t s) {
+  const uint32_t wh = w * h;
+  hipLaunchKernelGGL(k_resolve, dim3(grid_for(wh, 0)), dim3(256), 0, s, wb.st_L, accum, wh, samples_in_batch, wb.counters, wb.stats,
+                     num_bounces);
+}
+
+void launch_set_count(uint32_t* counter, uint32_t value, hipStream_t s) {
+  hipLaunchKernelGGL(k_set_count, dim3(1), dim3(1), 0, s, counter, value);
+}
+
+void launch_debug_eval(int fn, const PtRtConsts& c, const uint2* lut, const float* in, uint64_t n, float* out, hipStream_t s) {
+  hipLaunchKernelGGL(k_debug_eval, dim3(grid_for(n, 0)), dim3(256), 0, s, fn, c, lut, in, n, out);
+}
+
+}  // namespace pt

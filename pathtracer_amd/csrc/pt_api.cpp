@@ -1,0 +1,594 @@
+// pt_api.cpp — the C-ABI of libpathtracer_amd.so (declared in include/pt_api.h).
+// Host side of the hot path: what PathTracer::InitRtScene / RenderRT / RestartAccumulation / UpdateOutputTexture and
+// Sky::ComputeTranmittanceLut do through the FANCY RenderCore in the reference (PathTracer/PathTracer.cpp:171-339,
+// 659-787,834-878,912-915; Sky.cpp:127-148) is done here with plain HIP runtime calls on one stream.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../include/pt_api.h"
+#include "bvh_builder.h"
+#include "kernels.h"
+#include "scene_flatten.h"
+
+using namespace pt;
+
+static thread_local std::string g_create_error;
+
+struct pt_ctx {
+  int device = 0;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  std::string err;
+  LaunchCfg cfg;
+
+  // scene
+  bool has_scene = false;
+  DeviceScene ds;
+  std::vector<void*> scene_allocs;
+  PtSceneInfo info{};
+
+  // sky
+  uint2* lut = nullptr;
+  bool has_sky = false;
+
+  // accumulation target
+  float4* accum = nullptr;
+  bool accum_owned = false;
+  uint32_t width = 0, height = 0;
+  uint64_t num_samples = 0;
+
+  // wavefront state
+  WavefrontBuffers wb;
+  std::vector<void*> wb_allocs;
+  float4* tmp_rays = nullptr;   // staging for pt_trace_rays (AoS PtRay)
+  float4* tmp_hits = nullptr;
+  uint64_t tmp_capacity = 0;
+
+  // options
+  bool count_traversal = false;
+  bool time_kernels = false;
+  int64_t samples_per_batch = 0;
+  int sky_mode = 0;
+
+  // timing
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> extend_events, render_events, event_pool;
+  double extend_ms = 0.0, render_ms = 0.0;
+  uint64_t extend_launches = 0;
+
+  int fail(int code, const std::string& msg) {
+    err = msg;
+    return code;
+  }
+};
+
+#define PT_HIP(call)                                                                                   \
+  do {                                                                                                 \
+    hipError_t e__ = (call);                                                                           \
+    if (e__ != hipSuccess)                                                                             \
+      return ctx->fail(e__ == hipErrorOutOfMemory ? PT_ERR_OUT_OF_MEMORY : PT_ERR_HIP,                 \
+                       std::string(#call) + ": " + hipGetErrorString(e__));                            \
+  } while (0)
+
+#define PT_REQUIRE_CTX()                                         \
+  do {                                                           \
+    if (!ctx) return PT_ERR_INVALID_ARG;                         \
+    hipError_t e__ = hipSetDevice(ctx->device);                  \
+    if (e__ != hipSuccess) return ctx->fail(PT_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(e__)); \
+  } while (0)
+
+namespace {
+
+template <class T>
+int dev_alloc(pt_ctx* ctx, T** p, size_t count, std::vector<void*>* track) {
+  *p = nullptr;
+  if (count == 0) count = 1;
+  void* v = nullptr;
+  PT_HIP(hipMalloc(&v, count * sizeof(T)));
+  *p = (T*)v;
+  if (track) track->push_back(v);
+  return PT_OK;
+}
+
+void free_list(std::vector<void*>& l) {
+  for (void* p : l) (void)hipFree(p);
+  l.clear();
+}
+
+std::pair<hipEvent_t, hipEvent_t> get_event_pair(pt_ctx* ctx) {
+  if (!ctx->event_pool.empty()) {
+    auto p = ctx->event_pool.back();
+    ctx->event_pool.pop_back();
+    return p;
+  }
+  hipEvent_t a = nullptr, b = nullptr;
+  (void)hipEventCreate(&a);
+  (void)hipEventCreate(&b);
+  return {a, b};
+}
+
+// Fold finished event pairs into the running sums (call after the stream is synchronised).
+void collect_events(pt_ctx* ctx) {
+  for (auto& p : ctx->extend_events) {
+    float ms = 0.0f;
+    if (hipEventElapsedTime(&ms, p.first, p.second) == hipSuccess) ctx->extend_ms += ms;
+    ctx->event_pool.push_back(p);
+  }
+  ctx->extend_events.clear();
+  for (auto& p : ctx->render_events) {
+    float ms = 0.0f;
+    if (hipEventElapsedTime(&ms, p.first, p.second) == hipSuccess) ctx->render_ms += ms;
+    ctx->event_pool.push_back(p);
+  }
+  ctx->render_events.clear();
+}
+
+int ensure_wavefront(pt_ctx* ctx, uint64_t paths) {
+  if (ctx->wb.capacity >= paths && ctx->wb.counters) return PT_OK;
+  PT_HIP(hipStreamSynchronize(ctx->stream));
+  unsigned long long* stats = ctx->wb.stats;  // statistics survive a re-allocation
+  std::vector<void*> keep;
+  for (void* p : ctx->wb_allocs)
+    if (p == (void*)stats) keep.push_back(p); else (void)hipFree(p);
+  ctx->wb_allocs = keep;
+  ctx->wb = WavefrontBuffers();
+  ctx->wb.stats = stats;
+  int rc;
+  for (int k = 0; k < 2; ++k) {
+    if ((rc = dev_alloc(ctx, &ctx->wb.ray_o[k], paths, &ctx->wb_allocs))) return rc;
+    if ((rc = dev_alloc(ctx, &ctx->wb.ray_d[k], paths, &ctx->wb_allocs))) return rc;
+    if ((rc = dev_alloc(ctx, &ctx->wb.qid[k], paths, &ctx->wb_allocs))) return rc;
+  }
+  if ((rc = dev_alloc(ctx, &ctx->wb.hits, paths, &ctx->wb_allocs))) return rc;
+  if ((rc = dev_alloc(ctx, &ctx->wb.st_T, paths, &ctx->wb_allocs))) return rc;
+  if ((rc = dev_alloc(ctx, &ctx->wb.st_L, paths, &ctx->wb_allocs))) return rc;
+  if ((rc = dev_alloc(ctx, &ctx->wb.sky_o, paths, &ctx->wb_allocs))) return rc;
+  if ((rc = dev_alloc(ctx, &ctx->wb.sky_d, paths, &ctx->wb_allocs))) return rc;
+  if ((rc = dev_alloc(ctx, &ctx->wb.counters, (size_t)CTR_WORDS, &ctx->wb_allocs))) return rc;
+  if (!ctx->wb.stats) {
+    if ((rc = dev_alloc(ctx, &ctx->wb.stats, (size_t)ST_WORDS, &ctx->wb_allocs))) return rc;
+    PT_HIP(hipMemsetAsync(ctx->wb.stats, 0, ST_WORDS * sizeof(unsigned long long), ctx->stream));
+  }
+  ctx->wb.capacity = paths;
+  return PT_OK;
+}
+
+int ensure_tmp(pt_ctx* ctx, uint64_t rays) {
+  if (ctx->tmp_capacity >= rays) return PT_OK;
+  PT_HIP(hipStreamSynchronize(ctx->stream));
+  if (ctx->tmp_rays) (void)hipFree(ctx->tmp_rays);
+  if (ctx->tmp_hits) (void)hipFree(ctx->tmp_hits);
+  ctx->tmp_rays = nullptr; ctx->tmp_hits = nullptr; ctx->tmp_capacity = 0;
+  int rc;
+  if ((rc = dev_alloc(ctx, &ctx->tmp_rays, rays * 2, nullptr))) return rc;
+  if ((rc = dev_alloc(ctx, &ctx->tmp_hits, rays, nullptr))) return rc;
+  ctx->tmp_capacity = rays;
+  return PT_OK;
+}
+
+int check_consts(pt_ctx* ctx, const PtRtConsts* c, bool need_sky) {
+  if (!c) return ctx->fail(PT_ERR_INVALID_ARG, "consts is null");
+  if (c->myMaxRecursionDepth > 62u) return ctx->fail(PT_ERR_INVALID_ARG, "myMaxRecursionDepth > 62 is not supported");
+  if (need_sky && c->mySampleSky && !ctx->has_sky) return ctx->fail(PT_ERR_NO_SKY, "mySampleSky is set but pt_sky_set has not been called");
+  return PT_OK;
+}
+
+void extend_one(pt_ctx* ctx, const float4* ro, const float4* rd, uint32_t stride, float4* hits, const uint32_t* count, uint32_t* cursor) {
+  std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
+  if (ctx->time_kernels) {
+    ev = get_event_pair(ctx);
+    (void)hipEventRecord(ev.first, ctx->stream);
+  }
+  launch_extend(ctx->ds, ro, rd, stride, hits, count, cursor, ctx->wb.stats, ctx->count_traversal, ctx->cfg, ctx->stream);
+  ctx->extend_launches++;
+  if (ctx->time_kernels) {
+    (void)hipEventRecord(ev.second, ctx->stream);
+    ctx->extend_events.push_back(ev);
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int pt_create(int device, pt_ctx** out_ctx) {
+  if (!out_ctx) { g_create_error = "pt_create: out_ctx is null"; return PT_ERR_INVALID_ARG; }
+  *out_ctx = nullptr;
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0) {
+    g_create_error = std::string("pt_create: no HIP device (") + hipGetErrorString(e) + ")";
+    return PT_ERR_NO_DEVICE;
+  }
+  if (device < 0 || device >= n) { g_create_error = "pt_create: device index out of range"; return PT_ERR_NO_DEVICE; }
+  if ((e = hipSetDevice(device)) != hipSuccess) { g_create_error = std::string("hipSetDevice: ") + hipGetErrorString(e); return PT_ERR_HIP; }
+  pt_ctx* ctx = new pt_ctx();
+  ctx->device = device;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->cfg.num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  if ((e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking)) != hipSuccess) {
+    g_create_error = std::string("hipStreamCreate: ") + hipGetErrorString(e);
+    delete ctx;
+    return PT_ERR_HIP;
+  }
+  ctx->stream = ctx->own_stream;
+  ctx->cfg.stream_blocks = ctx->cfg.num_cus * 8;
+  ctx->cfg.extend_blocks = ctx->cfg.num_cus * 4;
+  *out_ctx = ctx;
+  return PT_OK;
+}
+
+int pt_destroy(pt_ctx* ctx) {
+  if (!ctx) return PT_ERR_INVALID_ARG;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  collect_events(ctx);
+  for (auto& p : ctx->event_pool) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
+  free_list(ctx->scene_allocs);
+  free_list(ctx->wb_allocs);
+  if (ctx->tmp_rays) (void)hipFree(ctx->tmp_rays);
+  if (ctx->tmp_hits) (void)hipFree(ctx->tmp_hits);
+  if (ctx->lut) (void)hipFree(ctx->lut);
+  if (ctx->accum && ctx->accum_owned) (void)hipFree(ctx->accum);
+  if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+  delete ctx;
+  return PT_OK;
+}
+
+const char* pt_last_error(const pt_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int pt_set_stream(pt_ctx* ctx, void* hip_stream) {
+  PT_REQUIRE_CTX();
+  PT_HIP(hipStreamSynchronize(ctx->stream));
+  ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+  return PT_OK;
+}
+
+int pt_synchronize(pt_ctx* ctx) {
+  PT_REQUIRE_CTX();
+  PT_HIP(hipStreamSynchronize(ctx->stream));
+  return PT_OK;
+}
+
+int pt_set_option(pt_ctx* ctx, int option, int64_t value) {
+  PT_REQUIRE_CTX();
+  switch (option) {
+    case PT_OPT_COUNT_TRAVERSAL: ctx->count_traversal = value != 0; return PT_OK;
+    case PT_OPT_TIME_KERNELS: ctx->time_kernels = value != 0; return PT_OK;
+    case PT_OPT_SAMPLES_PER_BATCH:
+      if (value < 0 || value > 4096) return ctx->fail(PT_ERR_INVALID_ARG, "samples per batch must be 0..4096");
+      ctx->samples_per_batch = value;
+      return PT_OK;
+    case PT_OPT_SKY_MODE:
+      if (value != 0) return ctx->fail(PT_ERR_UNSUPPORTED, "only sky mode 0 (ray-march on every miss) is implemented");
+      ctx->sky_mode = 0;
+      return PT_OK;
+    default: return ctx->fail(PT_ERR_INVALID_ARG, "unknown option");
+  }
+}
+
+int pt_scene_create(pt_ctx* ctx, const PtMeshDesc* meshes, uint32_t num_meshes, const PtInstanceDesc* instances,
+                    uint32_t num_instances, const PtMaterial* materials, uint32_t num_materials, uint32_t flags) {
+  PT_REQUIRE_CTX();
+  FlatScene fs;
+  std::string err;
+  int rc = flatten_scene(meshes, num_meshes, instances, num_instances, materials, num_materials, flags, fs, err);
+  if (rc != PT_OK) return ctx->fail(rc, err);
+  Bvh8 bvh;
+  build_bvh8(fs.tri_verts.data(), fs.num_triangles(), bvh);
+
+  PT_HIP(hipStreamSynchronize(ctx->stream));
+  free_list(ctx->scene_allocs);
+  ctx->has_scene = false;
+  ctx->ds = DeviceScene();
+
+  uint4 *d_nodes, *d_tris, *d_prim;
+  float4 *d_vn, *d_mat;
+  float2* d_uv;
+  uint32_t* d_im;
+  if ((rc = dev_alloc(ctx, &d_nodes, bvh.nodes.size() * 5, &ctx->scene_allocs))) return rc;
+  if ((rc = dev_alloc(ctx, &d_tris, bvh.tris.size() * 3, &ctx->scene_allocs))) return rc;
+  if ((rc = dev_alloc(ctx, &d_prim, (size_t)fs.num_triangles(), &ctx->scene_allocs))) return rc;
+  if ((rc = dev_alloc(ctx, &d_vn, (size_t)fs.num_vertices(), &ctx->scene_allocs))) return rc;
+  if ((rc = dev_alloc(ctx, &d_uv, (size_t)fs.num_vertices(), &ctx->scene_allocs))) return rc;
+  if ((rc = dev_alloc(ctx, &d_im, fs.instance_material.size(), &ctx->scene_allocs))) return rc;
+  if ((rc = dev_alloc(ctx, &d_mat, (size_t)num_materials, &ctx->scene_allocs))) return rc;
+  auto up = [&](void* dst, const void* src, size_t bytes) -> hipError_t {
+    return bytes ? hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice) : hipSuccess;
+  };
+  PT_HIP(up(d_nodes, bvh.nodes.data(), bvh.nodes.size() * sizeof(PtBvh8Node)));
+  PT_HIP(up(d_tris, bvh.tris.data(), bvh.tris.size() * sizeof(PtTriRecord)));
+  PT_HIP(up(d_prim, fs.prim_data.data(), fs.prim_data.size() * 4));
+  PT_HIP(up(d_vn, fs.vertex_normal.data(), fs.vertex_normal.size() * 4));
+  PT_HIP(up(d_uv, fs.vertex_uv.data(), fs.vertex_uv.size() * 4));
+  PT_HIP(up(d_im, fs.instance_material.data(), fs.instance_material.size() * 4));
+  PT_HIP(up(d_mat, fs.materials.data(), fs.materials.size() * 4));
+
+  ctx->ds.nodes = d_nodes;
+  ctx->ds.tris = d_tris;
+  ctx->ds.prim_data = d_prim;
+  ctx->ds.vertex_normal = d_vn;
+  ctx->ds.vertex_uv = d_uv;
+  ctx->ds.instance_material = d_im;
+  ctx->ds.materials = d_mat;
+  ctx->ds.stack_entries = bvh.max_depth + 2;
+  if (extend_lds_bytes(ctx->ds.stack_entries) > 64 * 1024)
+    return ctx->fail(PT_ERR_UNSUPPORTED, "BVH deeper than the LDS traversal stack supports (" + std::to_string(bvh.max_depth) + " levels)");
+  ctx->cfg.extend_blocks = ctx->cfg.num_cus * std::max(1, std::min(8, extend_occupancy_blocks(ctx->ds.stack_entries)));
+
+  PtSceneInfo& in = ctx->info;
+  in.num_triangles = fs.num_triangles();
+  in.num_vertices = fs.num_vertices();
+  in.num_instances = num_instances;
+  in.num_materials = num_materials;
+  in.num_bvh_nodes = (uint32_t)bvh.nodes.size();
+  in.bvh_max_depth = bvh.max_depth;
+  in.bvh_bytes = bvh.nodes.size() * sizeof(PtBvh8Node) + bvh.tris.size() * sizeof(PtTriRecord);
+  for (int a = 0; a < 3; ++a) { in.bounds_min[a] = bvh.lo[a]; in.bounds_max[a] = bvh.hi[a]; }
+  in.build_ms = bvh.build_ms;
+  ctx->has_scene = true;
+  return PT_OK;
+}
+
+int pt_scene_info(const pt_ctx* ctx, PtSceneInfo* out) {
+  if (!ctx || !out) return PT_ERR_INVALID_ARG;
+  if (!ctx->has_scene) return PT_ERR_NO_SCENE;
+  *out = ctx->info;
+  return PT_OK;
+}
+
+int pt_sky_set(pt_ctx* ctx, const PtAtmosphere* atmosphere) {
+  PT_REQUIRE_CTX();
+  if (!atmosphere) return ctx->fail(PT_ERR_INVALID_ARG, "atmosphere is null");
+  if (!ctx->lut) {
+    void* v = nullptr;
+    PT_HIP(hipMalloc(&v, 256 * 64 * sizeof(uint2)));
+    ctx->lut = (uint2*)v;
+  }
+  launch_transmittance_lut(*atmosphere, ctx->lut, ctx->stream);
+  PT_HIP(hipGetLastError());
+  ctx->has_sky = true;
+  return PT_OK;
+}
+
+int pt_sky_lut_read(pt_ctx* ctx, uint16_t* rgba16f) {
+  PT_REQUIRE_CTX();
+  if (!rgba16f) return ctx->fail(PT_ERR_INVALID_ARG, "output pointer is null");
+  if (!ctx->has_sky) return ctx->fail(PT_ERR_NO_SKY, "pt_sky_set has not been called");
+  PT_HIP(hipMemcpyAsync(rgba16f, ctx->lut, 256 * 64 * sizeof(uint2), hipMemcpyDeviceToHost, ctx->stream));
+  PT_HIP(hipStreamSynchronize(ctx->stream));
+  return PT_OK;
+}
+
+int pt_accum_reset(pt_ctx* ctx, uint32_t width, uint32_t height) {
+  PT_REQUIRE_CTX();
+  if (width == 0 || height == 0 || (uint64_t)width * height > (1ull << 28)) return ctx->fail(PT_ERR_INVALID_ARG, "bad target size");
+  if (!ctx->accum || !ctx->accum_owned || ctx->width != width || ctx->height != height) {
+    PT_HIP(hipStreamSynchronize(ctx->stream));  // WaitForIdle before re-creating the texture (PathTracer.cpp:835)
+    if (ctx->accum && ctx->accum_owned) (void)hipFree(ctx->accum);
+    ctx->accum = nullptr;
+    void* v = nullptr;
+    PT_HIP(hipMalloc(&v, (size_t)width * height * sizeof(float4)));
+    ctx->accum = (float4*)v;
+    ctx->accum_owned = true;
+    ctx->width = width;
+    ctx->height = height;
+  }
+  PT_HIP(hipMemsetAsync(ctx->accum, 0, (size_t)width * height * sizeof(float4), ctx->stream));  // clear_texture.hlsl:8-12
+  ctx->num_samples = 0;
+  return PT_OK;
+}
+
+int pt_accum_bind(pt_ctx* ctx, float* device_rgba, uint32_t width, uint32_t height) {
+  PT_REQUIRE_CTX();
+  if (!device_rgba) {
+    if (ctx->accum && !ctx->accum_owned) { ctx->accum = nullptr; ctx->width = ctx->height = 0; ctx->num_samples = 0; }
+    return PT_OK;
+  }
+  if (width == 0 || height == 0 || (uint64_t)width * height > (1ull << 28)) return ctx->fail(PT_ERR_INVALID_ARG, "bad target size");
+  if (((uintptr_t)device_rgba & 15u) != 0) return ctx->fail(PT_ERR_INVALID_ARG, "target must be 16-byte aligned");
+  PT_HIP(hipStreamSynchronize(ctx->stream));
+  if (ctx->accum && ctx->accum_owned) (void)hipFree(ctx->accum);
+  ctx->accum = (float4*)device_rgba;
+  ctx->accum_owned = false;
+  ctx->width = width;
+  ctx->height = height;
+  PT_HIP(hipMemsetAsync(ctx->accum, 0, (size_t)width * height * sizeof(float4), ctx->stream));
+  ctx->num_samples = 0;
+  return PT_OK;
+}
+
+int pt_accum_device_ptr(pt_ctx* ctx, float** device_rgba, uint64_t* num_samples) {
+  PT_REQUIRE_CTX();
+  if (!ctx->accum) return ctx->fail(PT_ERR_NO_TARGET, "no accumulation target");
+  if (device_rgba) *device_rgba = (float*)ctx->accum;
+  if (num_samples) *num_samples = ctx->num_samples;
+  return PT_OK;
+}
+
+int pt_accum_set_count(pt_ctx* ctx, uint64_t num_samples) {
+  PT_REQUIRE_CTX();
+  if (!ctx->accum) return ctx->fail(PT_ERR_NO_TARGET, "no accumulation target");
+  ctx->num_samples = num_samples;
+  return PT_OK;
+}
+
+int pt_accum_read_sum(pt_ctx* ctx, float* host_rgba_sum, uint64_t* num_samples) {
+  PT_REQUIRE_CTX();
+  if (!ctx->accum) return ctx->fail(PT_ERR_NO_TARGET, "no accumulation target");
+  if (!host_rgba_sum) return ctx->fail(PT_ERR_INVALID_ARG, "output pointer is null");
+  PT_HIP(hipMemcpyAsync(host_rgba_sum, ctx->accum, (size_t)ctx->width * ctx->height * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
+  PT_HIP(hipStreamSynchronize(ctx->stream));
+  if (num_samples) *num_samples = ctx->num_samples;
+  return PT_OK;
+}
+
+int pt_accum_read(pt_ctx* ctx, float* host_rgba_mean) {
+  uint64_t n = 0;
+  int rc = pt_accum_read_sum(ctx, host_rgba_mean, &n);
+  if (rc != PT_OK) return rc;
+  if (n > 0) {
+    const float fn = (float)n;
+    const size_t cnt = (size_t)ctx->width * ctx->height * 4;
+    for (size_t i = 0; i < cnt; ++i) host_rgba_mean[i] = host_rgba_mean[i] / fn;
+  }
+  return PT_OK;
+}
+
+int pt_render(pt_ctx* ctx, const PtRtConsts* consts, uint32_t width, uint32_t height, uint32_t first_sample, uint32_t num_samples) {
+  PT_REQUIRE_CTX();
+  int rc = check_consts(ctx, consts, true);
+  if (rc != PT_OK) return rc;
+  if (!ctx->has_scene) return ctx->fail(PT_ERR_NO_SCENE, "pt_render before pt_scene_create");
+  if (!ctx->accum) return ctx->fail(PT_ERR_NO_TARGET, "pt_render before pt_accum_reset / pt_accum_bind");
+  if (width != ctx->width || height != ctx->height) return ctx->fail(PT_ERR_SIZE_MISMATCH, "w,h differ from the accumulation target");
+  if (num_samples == 0) return PT_OK;
+  if ((uint64_t)first_sample + num_samples > 0xFFFFFFFFull) return ctx->fail(PT_ERR_INVALID_ARG, "sample index overflows 32 bits");
+
+  const uint64_t wh = (uint64_t)width * height;
+  uint64_t spb = ctx->samples_per_batch > 0 ? (uint64_t)ctx->samples_per_batch : std::max<uint64_t>(1, (1ull << 23) / wh);
+  spb = std::min<uint64_t>(spb, num_samples);
+  spb = std::min<uint64_t>(spb, std::max<uint64_t>(1, ((1ull << 31) - 1) / wh));
+  if ((rc = ensure_wavefront(ctx, wh * spb)) != PT_OK) return rc;
+
+  std::pair<hipEvent_t, hipEvent_t> rev{nullptr, nullptr};
+  if (ctx->time_kernels) {
+    rev = get_event_pair(ctx);
+    PT_HIP(hipEventRecord(rev.first, ctx->stream));
+  }
+  const uint32_t bounces = consts->myMaxRecursionDepth + 1;  // inclusive loop bound (PathTracing.hlsl:68)
+  for (uint32_t done = 0; done < num_samples;) {
+    const uint32_t k = (uint32_t)std::min<uint64_t>(spb, num_samples - done);
+    const uint64_t paths = wh * k;
+    PT_HIP(hipMemsetAsync(ctx->wb.counters, 0, CTR_WORDS * sizeof(uint32_t), ctx->stream));
+    launch_generate(*consts, ctx->wb, width, height, first_sample + done, k, ctx->stream);
+    for (uint32_t b = 0; b < bounces; ++b) {
+      const int in = (int)(b & 1u);
+      extend_one(ctx, ctx->wb.ray_o[in], ctx->wb.ray_d[in], 1, ctx->wb.hits, ctx->wb.counters + CTR_QCOUNT0 + b, ctx->wb.counters + CTR_WORK0 + b);
+      launch_shade(*consts, ctx->ds, ctx->wb, (int)b, width, height, first_sample + done, paths, ctx->cfg, ctx->stream);
+    }
+    if (consts->mySampleSky) launch_sky(*consts, ctx->lut, ctx->wb, paths, ctx->cfg, ctx->stream);
+    launch_resolve(ctx->wb, ctx->accum, width, height, k, bounces, ctx->stream);
+    done += k;
+  }
+  PT_HIP(hipGetLastError());
+  if (ctx->time_kernels) {
+    PT_HIP(hipEventRecord(rev.second, ctx->stream));
+    ctx->render_events.push_back(rev);
+  }
+  ctx->num_samples += num_samples;
+  return PT_OK;
+}
+
+int pt_primary_hits(pt_ctx* ctx, const PtRtConsts* consts, uint32_t width, uint32_t height, uint32_t sample, PtHit* hits) {
+  PT_REQUIRE_CTX();
+  int rc = check_consts(ctx, consts, false);
+  if (rc != PT_OK) return rc;
+  if (!ctx->has_scene) return ctx->fail(PT_ERR_NO_SCENE, "pt_primary_hits before pt_scene_create");
+  if (!hits || width == 0 || height == 0 || (uint64_t)width * height > (1ull << 28)) return ctx->fail(PT_ERR_INVALID_ARG, "bad arguments");
+  const uint64_t wh = (uint64_t)width * height;
+  if ((rc = ensure_wavefront(ctx, wh)) != PT_OK) return rc;
+  PT_HIP(hipMemsetAsync(ctx->wb.counters, 0, CTR_WORDS * sizeof(uint32_t), ctx->stream));
+  launch_generate(*consts, ctx->wb, width, height, sample, 1, ctx->stream);
+  extend_one(ctx, ctx->wb.ray_o[0], ctx->wb.ray_d[0], 1, ctx->wb.hits, ctx->wb.counters + CTR_QCOUNT0, ctx->wb.counters + CTR_WORK0);
+  PT_HIP(hipGetLastError());
+  PT_HIP(hipMemcpyAsync(hits, ctx->wb.hits, wh * sizeof(PtHit), hipMemcpyDeviceToHost, ctx->stream));
+  PT_HIP(hipStreamSynchronize(ctx->stream));
+  return PT_OK;
+}
+
+int pt_trace_rays_device(pt_ctx* ctx, const PtRay* device_rays, uint64_t num_rays, PtHit* device_hits) {
+  PT_REQUIRE_CTX();
+  if (!ctx->has_scene) return ctx->fail(PT_ERR_NO_SCENE, "pt_trace_rays before pt_scene_create");
+  if (num_rays == 0) return PT_OK;
+  if (!device_rays || !device_hits || num_rays >= (1ull << 31)) return ctx->fail(PT_ERR_INVALID_ARG, "bad arguments");
+  int rc;
+  if ((rc = ensure_wavefront(ctx, 1)) != PT_OK) return rc;
+  PT_HIP(hipMemsetAsync(ctx->wb.counters, 0, CTR_WORDS * sizeof(uint32_t), ctx->stream));
+  launch_set_count(ctx->wb.counters + CTR_QCOUNT0, (uint32_t)num_rays, ctx->stream);
+  const float4* base = (const float4*)device_rays;  // AoS: {origin,tmin},{dir,tmax}
+  extend_one(ctx, base, base + 1, 2, (float4*)device_hits, ctx->wb.counters + CTR_QCOUNT0, ctx->wb.counters + CTR_WORK0);
+  PT_HIP(hipGetLastError());
+  return PT_OK;
+}
+
+int pt_trace_rays(pt_ctx* ctx, const PtRay* rays, uint64_t num_rays, PtHit* hits) {
+  PT_REQUIRE_CTX();
+  if (!ctx->has_scene) return ctx->fail(PT_ERR_NO_SCENE, "pt_trace_rays before pt_scene_create");
+  if (num_rays == 0) return PT_OK;
+  if (!rays || !hits || num_rays >= (1ull << 31)) return ctx->fail(PT_ERR_INVALID_ARG, "bad arguments");
+  int rc;
+  if ((rc = ensure_tmp(ctx, num_rays)) != PT_OK) return rc;
+  PT_HIP(hipMemcpyAsync(ctx->tmp_rays, rays, num_rays * sizeof(PtRay), hipMemcpyHostToDevice, ctx->stream));
+  if ((rc = pt_trace_rays_device(ctx, (const PtRay*)ctx->tmp_rays, num_rays, (PtHit*)ctx->tmp_hits)) != PT_OK) return rc;
+  PT_HIP(hipMemcpyAsync(hits, ctx->tmp_hits, num_rays * sizeof(PtHit), hipMemcpyDeviceToHost, ctx->stream));
+  PT_HIP(hipStreamSynchronize(ctx->stream));
+  return PT_OK;
+}
+
+int pt_debug_eval(pt_ctx* ctx, int fn, const PtRtConsts* consts, const float* in, uint64_t n, float* out) {
+  PT_REQUIRE_CTX();
+  static const int in_w[PT_FN_COUNT] = {4, 6, 4, 6, 10, 5, 9, 6, 4};
+  static const int out_w[PT_FN_COUNT] = {8, 1, 1, 4, 1, 3, 4, 3, 6};
+  if (fn < 0 || fn >= PT_FN_COUNT) return ctx->fail(PT_ERR_INVALID_ARG, "unknown function id");
+  if (n == 0) return PT_OK;
+  if (!in || !out) return ctx->fail(PT_ERR_INVALID_ARG, "null array");
+  PtRtConsts c;
+  if (consts) c = *consts; else memset(&c, 0, sizeof(c));
+  if (fn == PT_FN_SKY && c.mySampleSky && !ctx->has_sky) return ctx->fail(PT_ERR_NO_SKY, "pt_sky_set has not been called");
+  float *d_in = nullptr, *d_out = nullptr;
+  int rc;
+  if ((rc = dev_alloc(ctx, &d_in, n * in_w[fn], nullptr))) return rc;
+  if ((rc = dev_alloc(ctx, &d_out, n * out_w[fn], nullptr))) { (void)hipFree(d_in); return rc; }
+  hipError_t e = hipMemcpyAsync(d_in, in, n * in_w[fn] * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) {
+    launch_debug_eval(fn, c, ctx->lut, d_in, n, d_out, ctx->stream);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(out, d_out, n * out_w[fn] * sizeof(float), hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  (void)hipFree(d_in);
+  (void)hipFree(d_out);
+  if (e != hipSuccess) return ctx->fail(PT_ERR_HIP, std::string("pt_debug_eval: ") + hipGetErrorString(e));
+  return PT_OK;
+}
+
+int pt_stats_get(pt_ctx* ctx, PtStats* out) {
+  PT_REQUIRE_CTX();
+  if (!out) return ctx->fail(PT_ERR_INVALID_ARG, "output pointer is null");
+  memset(out, 0, sizeof(*out));
+  PT_HIP(hipStreamSynchronize(ctx->stream));
+  collect_events(ctx);
+  if (ctx->wb.stats) {
+    unsigned long long h[ST_WORDS];
+    PT_HIP(hipMemcpy(h, ctx->wb.stats, sizeof(h), hipMemcpyDeviceToHost));
+    out->samples = h[ST_SAMPLES];
+    out->rays = h[ST_RAYS];
+    out->shaded_hits = h[ST_SHADED];
+    out->sky_misses = h[ST_SKY];
+    out->nodes_visited = h[ST_NODES];
+    out->tris_tested = h[ST_TRIS];
+  }
+  out->extend_launches = ctx->extend_launches;
+  out->extend_ms = ctx->extend_ms;
+  out->render_ms = ctx->render_ms;
+  return PT_OK;
+}
+
+int pt_stats_reset(pt_ctx* ctx) {
+  PT_REQUIRE_CTX();
+  PT_HIP(hipStreamSynchronize(ctx->stream));
+  collect_events(ctx);
+  ctx->extend_ms = 0.0;
+  ctx->render_ms = 0.0;
+  ctx->extend_launches = 0;
+  if (ctx->wb.stats) PT_HIP(hipMemset(ctx->wb.stats, 0, ST_WORDS * sizeof(unsigned long long)));
+  return PT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,106 @@
+// shading_device.h — device restatement of the reference's RNG, camera ray, Fresnel, Lambert and modified-Phong
+// code (resources/shaders/raytracing/{Random,Common,brdfSampling}.hlsl). Citations name the HLSL lines.
+#pragma once
+#include "device_math.h"
+
+namespace ptd {
+
+// ---- Random.hlsl ----
+struct Rng { uint32_t x, y, z, w; };
+
+// pcg4d — Random.hlsl:45-62 (only .x is consumed by GetRand01; the last w update is dead and dropped)
+__device__ __forceinline__ uint32_t pcg4d_x(Rng v) {
+  v.x = v.x * 1664525u + 1013904223u;
+  v.y = v.y * 1664525u + 1013904223u;
+  v.z = v.z * 1664525u + 1013904223u;
+  v.w = v.w * 1664525u + 1013904223u;
+  v.x += v.y * v.w;
+  v.y += v.z * v.x;
+  v.z += v.x * v.y;
+  v.w += v.y * v.z;
+  v.x ^= v.x >> 16u;
+  v.y ^= v.y >> 16u;
+  v.z ^= v.z >> 16u;
+  v.w ^= v.w >> 16u;
+  v.x += v.y * v.w;
+  return v.x;
+}
+// uintToFloat — Random.hlsl:84-86
+__device__ __forceinline__ float uintToFloat(uint32_t x) { return __uint_as_float(0x3f800000u | (x >> 9)) - 1.0f; }
+// InitRNG — Random.hlsl:91-93 (frameNumber = sample index)
+__device__ __forceinline__ Rng InitRNG(uint32_t px, uint32_t py, uint32_t frame) { Rng r; r.x = px; r.y = py; r.z = frame; r.w = 0u; return r; }
+// GetRand01 — Random.hlsl:96-99
+__device__ __forceinline__ float GetRand01(Rng& s) {
+  s.w++;
+  return uintToFloat(pcg4d_x(s));
+}
+
+// ---- Common.hlsl ----
+// GetPrimaryRay — Common.hlsl:183-189
+__device__ __forceinline__ void GetPrimaryRay(v2 pixel, uint32_t resX, uint32_t resY, v3 corner, v3 xAxis, v3 yAxis, v3 camPos,
+                                              v3& origin, v3& dir) {
+  float vx = pixel.x / (float)resX;
+  float vy = pixel.y / (float)resY;
+  vy = 1.0f - vy;
+  origin = corner + xAxis * vx + yAxis * vy;
+  dir = normalize(origin - camPos);
+}
+// GetLuminance — Common.hlsl:191-194
+__device__ __forceinline__ float GetLuminance(v3 c) { return dot(c, mk3(0.2126f, 0.7152f, 0.0722f)); }
+// GetFresnelSchlick — Common.hlsl:196-201
+__device__ __forceinline__ float GetFresnelSchlick(v3 N, v3 V) {
+  const float f0 = 0.04f;
+  float cosTheta = fmaxf(0.0f, dot(N, V));
+  return saturate(f0 + (1.0f - f0) * hlsl_pow(1.0f - cosTheta, 5.0f));
+}
+// GetUniformRandomDirectionInSphere — Common.hlsl:129-135
+__device__ __forceinline__ v3 GetUniformRandomDirectionInSphere(v2 u) {
+  float phi = 2.0f * PT_PI * u.x;
+  float theta = 2.0f * acosf(sqrtf(1.0f - u.y));
+  return mk3(sinf(theta) * cosf(phi), sinf(theta) * sinf(phi), cosf(theta));
+}
+// GetCosineWeightedHemisphereDirection — Common.hlsl:137-141
+__device__ __forceinline__ v3 GetCosineWeightedHemisphereDirection(v2 u, v3 N) {
+  return normalize(N + GetUniformRandomDirectionInSphere(u));
+}
+// GetCoordinateFrame + TransformToNormalFrame — Common.hlsl:150-157,168-176 (rows of tbn dotted with dir, Q6)
+__device__ __forceinline__ v3 TransformToNormalFrame(v3 N, v3 dir) {
+  v3 side = fabsf(N.x) < 0.999f ? mk3(1.0f, 0.0f, 0.0f) : mk3(0.0f, 0.0f, 1.0f);
+  v3 z = normalize(cross(-N, -side));
+  v3 x = cross(z, N);
+  return mk3(dot(x, dir), dot(N, dir), dot(z, dir));
+}
+
+// ---- brdfSampling.hlsl ----
+// GetLambertianBRDF / GetLambertianPDF — brdfSampling.hlsl:6-14
+__device__ __forceinline__ v3 GetLambertianBRDF(v3 albedo, v3 N, v3 L) { return albedo * fmaxf(0.0f, dot(N, L)) * (1.0f / PT_PI); }
+__device__ __forceinline__ float GetLambertianPDF(v3 N, v3 L) { return fmaxf(0.0f, dot(N, L)) * (1.0f / PT_PI); }
+// EvaluateModifiedPhong — brdfSampling.hlsl:16-22
+__device__ __forceinline__ float EvaluateModifiedPhong(v3 N, v3 L, v3 V, float specularStrength, float specularPower) {
+  v3 R = normalize(reflect(-L, N));
+  float cosAlpha = fmaxf(0.0f, dot(R, V));
+  return specularStrength * ((specularPower + 2.0f) / PT_TWO_PI) * hlsl_pow(cosAlpha, specularPower) * fmaxf(0.0f, dot(N, L));
+}
+// SampleModifiedPhong — brdfSampling.hlsl:24-39
+__device__ __forceinline__ v3 SampleModifiedPhong(v2 u, v3 N, float specularPower, float& pdf) {
+  float cosTheta = hlsl_pow(1.0f - u.x, 1.0f / (2.0f + specularPower));
+  float sinTheta = sqrtf(1.0f - cosTheta * cosTheta);
+  float phi = PT_TWO_PI * u.y;
+  pdf = ((specularPower + 2.0f) / PT_TWO_PI) * hlsl_pow(cosTheta, specularPower);
+  v3 d = mk3(cosf(phi) * sinTheta, cosTheta, sinf(phi) * sinTheta);
+  return TransformToNormalFrame(N, d);
+}
+// EstimateSpecularRayProbability — brdfSampling.hlsl:41-49
+__device__ __forceinline__ float EstimateSpecularRayProbability(float specStrength, v3 baseColor, float fresnel) {
+  float spec = fresnel * specStrength;
+  float diffuse = (1.0f - fresnel) * GetLuminance(baseColor);
+  float sum = spec + diffuse;
+  float p = sum > 0.001f ? spec / sum : 0.0f;
+  return clampf(p, 0.1f, 0.9f);
+}
+// Decode_Unorm_RGBA (FANCY Encoding.h, absent): byte / 255, R in the low byte.
+__device__ __forceinline__ v3 DecodeUnormRGB(uint32_t c) {
+  return mk3((float)(c & 0xffu) / 255.0f, (float)((c >> 8) & 0xffu) / 255.0f, (float)((c >> 16) & 0xffu) / 255.0f);
+}
+
+}  // namespace ptd

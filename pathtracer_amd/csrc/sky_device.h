@@ -1,0 +1,291 @@
+// sky_device.h — device restatement of the reference atmosphere: resources/shaders/sky/Common.hlsl (cited as
+// sky/Common.hlsl:line), sky/compute_transmittance_lut.hlsl and raytracing/SampleSky.hlsl. Two instantiations of
+// IntegrateScatteredLuminance are reachable from the path-tracing pipeline and both are written out here:
+//   OPTICAL_DEPTH_ONLY / 40 fixed steps  -> transmittance LUT texel  (Sky.cpp:62-63,127-148)
+//   full / ground=false / 4..14 variable steps / Mie+Rayleigh phase -> sky radiance on a miss (SampleSky.hlsl:7-47)
+// The LUT is RGBA16F (Sky.cpp:73), sampled bilinear + clamp with float weights (D3D sampler precision is
+// hardware-defined; see DESIGN.md "adopted definitions").
+#pragma once
+#include "device_math.h"
+#include "../../include/pt_api.h"
+
+namespace ptd {
+
+#define PT_TLUT_W 256
+#define PT_TLUT_H 64
+#define PT_PLANET_RADIUS_OFFSET 10.0f   // sky/Common.hlsl:153
+
+struct Atmo {  // sky/Common.hlsl:7-43, same 112-byte layout as PtAtmosphere
+  v3 RayleighScattering; float RayleighDensityExpScale;
+  v3 AbsorptionExtinction; float BottomRadius;
+  v3 GroundAlbedo; float TopRadius;
+  v3 MieScattering; float MieDensityExpScale;
+  v3 MieExtinction; float MiePhaseG;
+  v3 MieAbsorption; float AbsorptionDensity0LayerWidth;
+  float AbsorptionDensity0ConstantTerm, AbsorptionDensity0LinearTerm;
+  float AbsorptionDensity1ConstantTerm, AbsorptionDensity1LinearTerm;
+};
+static_assert(sizeof(Atmo) == sizeof(PtAtmosphere), "atmosphere layout");
+
+// raySphereIntersectNearest — sky/Common.hlsl:75-101
+__device__ __forceinline__ float raySphereIntersectNearest(v3 r0, v3 rd, v3 s0, float sR) {
+  float a = dot(rd, rd);
+  v3 s0_r0 = r0 - s0;
+  float b = 2.0f * dot(rd, s0_r0);
+  float c = dot(s0_r0, s0_r0) - (sR * sR);
+  float delta = b * b - 4.0f * a * c;
+  if (delta < 0.0f || a == 0.0f) return -1.0f;
+  float sq = sqrtf(delta);
+  float sol0 = (-b - sq) / (2.0f * a);
+  float sol1 = (-b + sq) / (2.0f * a);
+  if (sol0 < 0.0f && sol1 < 0.0f) return -1.0f;
+  if (sol0 < 0.0f) return fmaxf(0.0f, sol1);
+  else if (sol1 < 0.0f) return fmaxf(0.0f, sol0);
+  return fmaxf(0.0f, fminf(sol0, sol1));
+}
+
+// LutTransmittanceParamsToUv — sky/Common.hlsl:103-117
+__device__ __forceinline__ v2 LutTransmittanceParamsToUv(float bottomR, float topR, float viewHeight, float mu) {
+  float H = sqrtf(fmaxf(0.0f, topR * topR - bottomR * bottomR));
+  float rho = sqrtf(fmaxf(0.0f, viewHeight * viewHeight - bottomR * bottomR));
+  float discriminant = viewHeight * viewHeight * (mu * mu - 1.0f) + topR * topR;
+  float d = fmaxf(0.0f, (-viewHeight * mu + sqrtf(discriminant)));
+  float d_min = topR - viewHeight;
+  float d_max = rho + H;
+  v2 uv;
+  uv.x = (d - d_min) / (d_max - d_min);
+  uv.y = rho / H;
+  return uv;
+}
+
+// UvToLutTransmittanceParams — sky/Common.hlsl:273-288
+__device__ __forceinline__ void UvToLutTransmittanceParams(const Atmo& A, float& viewHeight, float& mu, v2 uv) {
+  float x_mu = uv.x, x_r = uv.y;
+  float H = sqrtf(A.TopRadius * A.TopRadius - A.BottomRadius * A.BottomRadius);
+  float rho = H * x_r;
+  viewHeight = sqrtf(rho * rho + A.BottomRadius * A.BottomRadius);
+  float d_min = A.TopRadius - viewHeight;
+  float d_max = rho + H;
+  float d = d_min + x_mu * (d_max - d_min);
+  mu = d == 0.0f ? 1.0f : (H * H - rho * rho - d * d) / (2.0f * viewHeight * d);
+  mu = clampf(mu, -1.0f, 1.0f);
+}
+
+struct Medium { v3 scattering, extinction, scatteringMie, scatteringRay; };
+// sampleMediumRGB — sky/Common.hlsl:191-221
+__device__ __forceinline__ Medium sampleMediumRGB(v3 P, const Atmo& A) {
+  const float viewHeight = length(P) - A.BottomRadius;
+  const float densityMie = expf(A.MieDensityExpScale * viewHeight);
+  const float densityRay = expf(A.RayleighDensityExpScale * viewHeight);
+  const float densityOzo = saturate(viewHeight < A.AbsorptionDensity0LayerWidth
+                                        ? A.AbsorptionDensity0LinearTerm * viewHeight + A.AbsorptionDensity0ConstantTerm
+                                        : A.AbsorptionDensity1LinearTerm * viewHeight + A.AbsorptionDensity1ConstantTerm);
+  Medium s;
+  v3 scatteringMie = densityMie * A.MieScattering;
+  v3 extinctionMie = densityMie * A.MieExtinction;
+  v3 scatteringRay = densityRay * A.RayleighScattering;
+  v3 extinctionRay = scatteringRay + mk3(0.0f);
+  v3 scatteringOzo = mk3(0.0f);
+  v3 absorptionOzo = densityOzo * A.AbsorptionExtinction;
+  v3 extinctionOzo = scatteringOzo + absorptionOzo;
+  s.scatteringMie = scatteringMie;
+  s.scatteringRay = scatteringRay;
+  s.scattering = scatteringMie + scatteringRay + scatteringOzo;
+  s.extinction = extinctionMie + extinctionRay + extinctionOzo;
+  return s;
+}
+
+// hgPhase == CornetteShanksMiePhaseFunction — sky/Common.hlsl:246-255
+__device__ __forceinline__ float hgPhase(float g, float cosTheta) {
+  float k = 3.0f / (8.0f * PT_PI) * (1.0f - g * g) / (2.0f + g * g);
+  return k * (1.0f + cosTheta * cosTheta) / hlsl_pow(1.0f + g * g - 2.0f * g * -cosTheta, 1.5f);
+}
+// RayleighPhase — sky/Common.hlsl:267-271
+__device__ __forceinline__ float RayleighPhase(float cosTheta) {
+  float factor = 3.0f / (16.0f * PT_PI);
+  return factor * (1.0f + cosTheta * cosTheta);
+}
+
+// MoveToTopAtmosphere — sky/Common.hlsl:320-339
+__device__ __forceinline__ bool MoveToTopAtmosphere(v3& P, v3 viewDir, float topR) {
+  float viewHeight = length(P);
+  if (viewHeight > topR) {
+    float tTop = raySphereIntersectNearest(P, viewDir, mk3(0.0f), topR);
+    if (tTop >= 0.0f) {
+      v3 UpVector = P / viewHeight;
+      v3 UpOffset = UpVector * -PT_PLANET_RADIUS_OFFSET;
+      P = P + viewDir * tTop + UpOffset;
+    } else {
+      return false;
+    }
+  }
+  return true;
+}
+
+__device__ __forceinline__ float half_bits_to_float(uint32_t h) {
+  _Float16 f;
+  unsigned short s = (unsigned short)h;
+  __builtin_memcpy(&f, &s, 2);
+  return (float)f;
+}
+__device__ __forceinline__ uint32_t float_to_half_bits(float x) {
+  _Float16 f = (_Float16)x;  // v_cvt_f16_f32, round to nearest even, subnormals kept
+  unsigned short s;
+  __builtin_memcpy(&s, &f, 2);
+  return (uint32_t)s;
+}
+
+// SampleLevel(linearClamp, uv, 0).rgb of the RGBA16F transmittance LUT — sky/Common.hlsl:510-511
+__device__ __forceinline__ v3 SampleTransmittanceLut(const uint2* __restrict__ lut, v2 uv) {
+  float x = clampf(uv.x * (float)PT_TLUT_W - 0.5f, 0.0f, (float)(PT_TLUT_W - 1));
+  float y = clampf(uv.y * (float)PT_TLUT_H - 0.5f, 0.0f, (float)(PT_TLUT_H - 1));
+  int x0 = (int)floorf(x), y0 = (int)floorf(y);
+  float fx = x - (float)x0, fy = y - (float)y0;
+  int x1 = x0 + 1 < PT_TLUT_W ? x0 + 1 : PT_TLUT_W - 1;
+  int y1 = y0 + 1 < PT_TLUT_H ? y0 + 1 : PT_TLUT_H - 1;
+  uint2 t00 = lut[y0 * PT_TLUT_W + x0], t10 = lut[y0 * PT_TLUT_W + x1];
+  uint2 t01 = lut[y1 * PT_TLUT_W + x0], t11 = lut[y1 * PT_TLUT_W + x1];
+  float gx = 1.0f - fx, gy = 1.0f - fy;
+  v3 r;
+  {
+    float top = half_bits_to_float(t00.x & 0xffffu) * gx + half_bits_to_float(t10.x & 0xffffu) * fx;
+    float bot = half_bits_to_float(t01.x & 0xffffu) * gx + half_bits_to_float(t11.x & 0xffffu) * fx;
+    r.x = top * gy + bot * fy;
+  }
+  {
+    float top = half_bits_to_float(t00.x >> 16) * gx + half_bits_to_float(t10.x >> 16) * fx;
+    float bot = half_bits_to_float(t01.x >> 16) * gx + half_bits_to_float(t11.x >> 16) * fx;
+    r.y = top * gy + bot * fy;
+  }
+  {
+    float top = half_bits_to_float(t00.y & 0xffffu) * gx + half_bits_to_float(t10.y & 0xffffu) * fx;
+    float bot = half_bits_to_float(t01.y & 0xffffu) * gx + half_bits_to_float(t11.y & 0xffffu) * fx;
+    r.z = top * gy + bot * fy;
+  }
+  return r;
+}
+
+// Sphere hits that bound the march — sky/Common.hlsl:388-411,428. Returns false when the ray leaves without
+// touching planet or atmosphere (the function returns a zero result there).
+__device__ __forceinline__ bool sky_tmax(v3 P, v3 dir, const Atmo& A, float& tMax) {
+  v3 earthO = mk3(0.0f);
+  float tBottom = raySphereIntersectNearest(P, dir, earthO, A.BottomRadius);
+  float tTop = raySphereIntersectNearest(P, dir, earthO, A.TopRadius);
+  tMax = 0.0f;
+  if (tBottom < 0.0f) {
+    if (tTop < 0.0f) return false;
+    tMax = tTop;
+  } else {
+    if (tTop > 0.0f) tMax = fminf(tTop, tBottom);
+  }
+  tMax = fminf(tMax, 9000000.0f);
+  return true;
+}
+
+// IntegrateScatteredLuminance, OPTICAL_DEPTH_ONLY instantiation — sky/Common.hlsl:368-589 with
+// VariableSampleCount=false, SampleCountIni=40 (compute_transmittance_lut.hlsl:30-56).
+__device__ __forceinline__ v3 IntegrateOpticalDepth(v3 P0, v3 dir, const Atmo& A) {
+  v3 OpticalDepth = mk3(0.0f);
+  float tMax;
+  if (!sky_tmax(P0, dir, A, tMax)) return OpticalDepth;
+  const float SampleCount = 40.0f;
+  float t = 0.0f;
+  const float SampleSegmentT = 0.3f;
+  for (float s = 0.0f; s < SampleCount; s += 1.0f) {
+    float NewT = tMax * (s + SampleSegmentT) / SampleCount;
+    float dt = NewT - t;
+    t = NewT;
+    v3 P = P0 + t * dir;
+    Medium medium = sampleMediumRGB(P, A);
+    v3 SampleOpticalDepth = medium.extinction * dt;
+    OpticalDepth = OpticalDepth + SampleOpticalDepth;
+  }
+  return OpticalDepth;
+}
+
+// compute_transmittance_lut.hlsl main — :15-62; returns the RGBA16F texel packed in a uint2.
+__device__ __forceinline__ uint2 TransmittanceLutTexel(const Atmo& A, uint32_t ix, uint32_t iy) {
+  v2 uv;
+  uv.x = ((float)ix + 0.5f) / (float)PT_TLUT_W;
+  uv.y = ((float)iy + 0.5f) / (float)PT_TLUT_H;
+  float viewHeight, mu;
+  UvToLutTransmittanceParams(A, viewHeight, mu, uv);
+  v3 pos = mk3(0.0f, viewHeight, 0.0f);
+  v3 dir = mk3(0.0f, mu, sqrtf(1.0f - mu * mu));
+  v3 od = IntegrateOpticalDepth(pos, dir, A);
+  v3 tr = exp3(-od);
+  uint2 r;
+  r.x = float_to_half_bits(tr.x) | (float_to_half_bits(tr.y) << 16);
+  r.y = float_to_half_bits(tr.z) | (float_to_half_bits(1.0f) << 16);
+  return r;
+}
+
+// IntegrateScatteredLuminance, full instantiation as called from SampleSkyLuminance — sky/Common.hlsl:368-589 with
+// ground=false, VariableSampleCount=true, MieRayPhase=true, DepthBufferValue=-1 (SampleSky.hlsl:21-41).
+__device__ __forceinline__ v3 IntegrateSkyLuminance(v3 P0, v3 dir, v3 sunDir, const Atmo& A, v2 minMaxSPP, v3 sunIlluminance,
+                                                    const uint2* __restrict__ lut) {
+  v3 L = mk3(0.0f);
+  float tMax;
+  if (!sky_tmax(P0, dir, A, tMax)) return L;
+  float SampleCount = lerpf(minMaxSPP.x, minMaxSPP.y, saturate(tMax * 0.01f));
+  float SampleCountFloor = floorf(SampleCount);
+  float tMaxFloor = tMax * SampleCountFloor / SampleCount;
+
+  float cosTheta = dot(sunDir, dir);
+  float MiePhaseValue = hgPhase(A.MiePhaseG, -cosTheta);
+  float RayleighPhaseValue = RayleighPhase(cosTheta);
+  v3 globalL = sunIlluminance;
+  v3 throughput = mk3(1.0f);
+  const float SampleSegmentT = 0.3f;
+  v3 earthO = mk3(0.0f);
+  for (float s = 0.0f; s < SampleCount; s += 1.0f) {
+    float t0 = (s) / SampleCountFloor;
+    float t1 = (s + 1.0f) / SampleCountFloor;
+    t0 = t0 * t0;
+    t1 = t1 * t1;
+    t0 = tMaxFloor * t0;
+    if (t1 > 1.0f) t1 = tMax;
+    else t1 = tMaxFloor * t1;
+    float t = t0 + (t1 - t0) * SampleSegmentT;
+    float dt = t1 - t0;
+    v3 P = P0 + t * dir;
+
+    Medium medium = sampleMediumRGB(P, A);
+    v3 SampleOpticalDepth = medium.extinction * dt;
+    v3 SampleTransmittance = exp3(-SampleOpticalDepth);
+
+    float pHeight = length(P);
+    v3 UpVector = P / pHeight;
+    float SunZenithCosAngle = dot(sunDir, UpVector);
+    v2 uv = LutTransmittanceParamsToUv(A.BottomRadius, A.TopRadius, pHeight, SunZenithCosAngle);
+    v3 TransmittanceToSun = SampleTransmittanceLut(lut, uv);
+
+    v3 PhaseTimesScattering = medium.scatteringMie * MiePhaseValue + medium.scatteringRay * RayleighPhaseValue;
+
+    float tEarth = raySphereIntersectNearest(P, sunDir, earthO + PT_PLANET_RADIUS_OFFSET * UpVector, A.BottomRadius);
+    float earthShadow = tEarth >= 0.0f ? 0.0f : 1.0f;
+    v3 multiScatteredLuminance = mk3(0.0f);
+    float shadow = 1.0f;
+    v3 S = globalL * (earthShadow * shadow * TransmittanceToSun * PhaseTimesScattering + multiScatteredLuminance * medium.scattering);
+    v3 Sint = (S - S * SampleTransmittance) / medium.extinction;
+    L = L + throughput * Sint;
+    throughput = throughput * SampleTransmittance;
+  }
+  return L;
+}
+
+// SampleSkyLuminance — SampleSky.hlsl:7-47
+__device__ __forceinline__ v3 SampleSkyLuminance(v3 viewPos, v3 viewDir, const PtRtConsts& c, const uint2* __restrict__ lut) {
+  if (!c.mySampleSky) return ld3(c.mySkyFallbackEmission);
+  Atmo A;
+  __builtin_memcpy(&A, &c.mySkyConsts.myAtmosphere, sizeof(A));
+  v3 worldPos = viewPos + mk3(0.0f, A.BottomRadius, 0.0f);
+  v3 sky = mk3(0.0f);
+  if (MoveToTopAtmosphere(worldPos, viewDir, A.TopRadius)) {
+    v2 mm; mm.x = c.mySkyConsts.myRayMarchMinMaxSPP[0]; mm.y = c.mySkyConsts.myRayMarchMinMaxSPP[1];
+    sky = IntegrateSkyLuminance(worldPos, viewDir, ld3(c.mySkyConsts.mySunDirection), A, mm, ld3(c.mySkyConsts.mySunIlluminance), lut);
+  }
+  return sky;
+}
+
+}  // namespace ptd

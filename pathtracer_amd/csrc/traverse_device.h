@@ -1,0 +1,180 @@
+// traverse_device.h — closest-hit traversal of the compressed 8-wide BVH (bvh8.h) with a per-lane stack in LDS and
+// the watertight ray/triangle test. This is the MI355X replacement for the DXR TraceRay call at
+// resources/shaders/raytracing/PathTracing.hlsl:71 (flags 0, mask 0xFF, opaque two-sided triangles,
+// tmin < t < tmax). Equal-t ties resolve to the lower global triangle id so the result is independent of
+// traversal order (and therefore of the acceleration structure).
+#pragma once
+#include "bvh8.h"
+#include "device_math.h"
+
+namespace ptd {
+
+struct TraceRay {
+  float ox, oy, oz, tmin;
+  float dx, dy, dz, tmax;
+};
+
+struct HitRec {
+  float t, u, v;
+  uint32_t prim;
+};
+
+__device__ __forceinline__ float sel3(float x, float y, float z, int k) { return k == 0 ? x : (k == 1 ? y : z); }
+
+// Watertight ray/triangle test (Woop, Benthin, Wald 2013), fp32 with the fp64 fallback for zero edge functions.
+// The operation order here is the contract shared with the CPU oracle: keep it literal, no fused ops.
+struct TriTester {
+  float ox, oy, oz;
+  int kx, ky, kz;
+  float Sx, Sy, Sz;
+  __device__ __forceinline__ void init(const TraceRay& r) {
+    ox = r.ox; oy = r.oy; oz = r.oz;
+    float ax = fabsf(r.dx), ay = fabsf(r.dy), az = fabsf(r.dz);
+    kz = 0; float m = ax;
+    if (ay > m) { kz = 1; m = ay; }
+    if (az > m) { kz = 2; }
+    kx = kz + 1; if (kx == 3) kx = 0;
+    ky = kx + 1; if (ky == 3) ky = 0;
+    float dz = sel3(r.dx, r.dy, r.dz, kz);
+    if (dz < 0.0f) { int t = kx; kx = ky; ky = t; }
+    Sx = sel3(r.dx, r.dy, r.dz, kx) / dz;
+    Sy = sel3(r.dx, r.dy, r.dz, ky) / dz;
+    Sz = 1.0f / dz;
+  }
+  __device__ __forceinline__ void test(const uint4& q0, const uint4& q1, const uint4& q2, float tmin, HitRec& best) const {
+    const float ax = __uint_as_float(q0.x) - ox, ay = __uint_as_float(q0.y) - oy, az = __uint_as_float(q0.z) - oz;
+    const float bx = __uint_as_float(q1.x) - ox, by = __uint_as_float(q1.y) - oy, bz = __uint_as_float(q1.z) - oz;
+    const float cx = __uint_as_float(q2.x) - ox, cy = __uint_as_float(q2.y) - oy, cz = __uint_as_float(q2.z) - oz;
+    const float Akz = sel3(ax, ay, az, kz), Bkz = sel3(bx, by, bz, kz), Ckz = sel3(cx, cy, cz, kz);
+    const float Ax = sel3(ax, ay, az, kx) - Sx * Akz, Ay = sel3(ax, ay, az, ky) - Sy * Akz;
+    const float Bx = sel3(bx, by, bz, kx) - Sx * Bkz, By = sel3(bx, by, bz, ky) - Sy * Bkz;
+    const float Cx = sel3(cx, cy, cz, kx) - Sx * Ckz, Cy = sel3(cx, cy, cz, ky) - Sy * Ckz;
+    float U = Cx * By - Cy * Bx;
+    float V = Ax * Cy - Ay * Cx;
+    float W = Bx * Ay - By * Ax;
+    if (U == 0.0f || V == 0.0f || W == 0.0f) {
+      double CxBy = (double)Cx * (double)By, CyBx = (double)Cy * (double)Bx;
+      U = (float)(CxBy - CyBx);
+      double AxCy = (double)Ax * (double)Cy, AyCx = (double)Ay * (double)Cx;
+      V = (float)(AxCy - AyCx);
+      double BxAy = (double)Bx * (double)Ay, ByAx = (double)By * (double)Ax;
+      W = (float)(BxAy - ByAx);
+    }
+    if ((U < 0.0f || V < 0.0f || W < 0.0f) && (U > 0.0f || V > 0.0f || W > 0.0f)) return;
+    const float det = U + V + W;
+    if (det == 0.0f) return;
+    const float Az = Sz * Akz, Bz = Sz * Bkz, Cz = Sz * Ckz;
+    const float T = U * Az + V * Bz + W * Cz;
+    const float rcpDet = 1.0f / det;
+    const float t = T * rcpDet;
+    if (!(t > tmin)) return;
+    const uint32_t prim = q0.w;
+    if (t < best.t || (t == best.t && prim < best.prim)) {
+      best.t = t;
+      best.u = V * rcpDet;
+      best.v = W * rcpDet;
+      best.prim = prim;
+    }
+  }
+};
+
+__device__ __forceinline__ float safe_dir(float d) { return fabsf(d) < 1e-25f ? copysignf(1e-25f, d) : d; }
+
+// Closest hit. `stk` points at this lane's slot of entry 0 of the wave's LDS stack; consecutive entries are
+// 64 slots apart (lane-contiguous, conflict-free ds_read_b64/ds_write_b64).
+template <bool COUNT>
+__device__ __forceinline__ HitRec trace_closest(const uint4* __restrict__ nodes, const uint4* __restrict__ tris,
+                                                const TraceRay& ray, uint2* stk, uint32_t& n_nodes, uint32_t& n_tris) {
+  HitRec best;
+  best.t = ray.tmax; best.u = 0.0f; best.v = 0.0f; best.prim = 0xFFFFFFFFu;
+  TriTester tt;
+  tt.init(ray);
+  const float sdx = safe_dir(ray.dx), sdy = safe_dir(ray.dy), sdz = safe_dir(ray.dz);
+  const float idx = 1.0f / sdx, idy = 1.0f / sdy, idz = 1.0f / sdz;
+  const bool negx = sdx < 0.0f, negy = sdy < 0.0f, negz = sdz < 0.0f;
+  const uint32_t oct = (negx ? 1u : 0u) | (negy ? 2u : 0u) | (negz ? 4u : 0u);
+  const uint32_t oct4 = oct * 0x01010101u;
+
+  uint2 ng = make_uint2(0u, 0x80000000u);  // root: one pending internal "child" at priority 7 of a group with base 0
+  uint2 tg = make_uint2(0u, 0u);
+  int sp = 0;
+  for (;;) {
+    if (ng.y > 0x00FFFFFFu) {
+      const uint32_t hits = ng.y;
+      const int b = 31 - __clz((int)hits);
+      ng.y &= ~(1u << b);
+      if (ng.y > 0x00FFFFFFu) { stk[sp * 64] = ng; ++sp; }
+      const uint32_t slot = ((uint32_t)b - 24u) ^ oct;
+      const uint32_t rel = __popc(hits & ~(0xFFFFFFFFu << slot));
+      const uint4* np = nodes + (size_t)(ng.x + rel) * 5;
+      const uint4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3], n4 = np[4];
+      if (COUNT) ++n_nodes;
+
+      const uint32_t e = n0.w;
+      const float ax = __uint_as_float((e & 0xffu) << 23) * idx;
+      const float ay = __uint_as_float(((e >> 8) & 0xffu) << 23) * idy;
+      const float az = __uint_as_float(((e >> 16) & 0xffu) << 23) * idz;
+      const float bx = (__uint_as_float(n0.x) - ray.ox) * idx;
+      const float by = (__uint_as_float(n0.y) - ray.oy) * idy;
+      const float bz = (__uint_as_float(n0.z) - ray.oz) * idz;
+
+      uint32_t hitmask = 0u;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const uint32_t meta4 = h ? n1.w : n1.z;
+        const uint32_t qlx = h ? n2.y : n2.x, qly = h ? n2.w : n2.z, qlz = h ? n3.y : n3.x;
+        const uint32_t qhx = h ? n3.w : n3.z, qhy = h ? n4.y : n4.x, qhz = h ? n4.w : n4.z;
+        const uint32_t nx = negx ? qhx : qlx, fx = negx ? qlx : qhx;
+        const uint32_t ny = negy ? qhy : qly, fy = negy ? qly : qhy;
+        const uint32_t nz = negz ? qhz : qlz, fz = negz ? qlz : qhz;
+        const uint32_t is_inner4 = (meta4 & (meta4 << 1)) & 0x10101010u;
+        const uint32_t inner_mask4 = (is_inner4 >> 4) * 0xffu;
+        const uint32_t bit_index4 = (meta4 ^ (oct4 & inner_mask4)) & 0x1f1f1f1fu;
+        const uint32_t child_bits4 = (meta4 >> 5) & 0x07070707u;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float tnx = __builtin_fmaf((float)((nx >> (8 * j)) & 0xffu), ax, bx);
+          const float tny = __builtin_fmaf((float)((ny >> (8 * j)) & 0xffu), ay, by);
+          const float tnz = __builtin_fmaf((float)((nz >> (8 * j)) & 0xffu), az, bz);
+          const float tfx = __builtin_fmaf((float)((fx >> (8 * j)) & 0xffu), ax, bx);
+          const float tfy = __builtin_fmaf((float)((fy >> (8 * j)) & 0xffu), ay, by);
+          const float tfz = __builtin_fmaf((float)((fz >> (8 * j)) & 0xffu), az, bz);
+          const float tn = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, ray.tmin));
+          const float tf = fminf(fminf(tfx, tfy), fminf(tfz, best.t));
+          // conservative: widen by ~8 ulp so fp32 rounding of the slab arithmetic can never cull a true hit
+          if (tn <= tf * 1.000001f) {
+            const uint32_t cb = (child_bits4 >> (8 * j)) & 0xffu;
+            const uint32_t bi = (bit_index4 >> (8 * j)) & 0xffu;
+            hitmask |= cb << bi;
+          }
+        }
+      }
+      ng.x = n1.x;
+      ng.y = (hitmask & 0xFF000000u) | (e >> 24);
+      tg.x = n1.y;
+      tg.y = hitmask & 0x00FFFFFFu;
+    } else {
+      tg = ng;
+      ng = make_uint2(0u, 0u);
+    }
+
+    while (tg.y != 0u) {
+      const int i = __ffs((int)tg.y) - 1;
+      tg.y &= tg.y - 1u;
+      const uint4* tp = tris + (size_t)(tg.x + (uint32_t)i) * 3;
+      const uint4 q0 = tp[0], q1 = tp[1], q2 = tp[2];
+      if (COUNT) ++n_tris;
+      tt.test(q0, q1, q2, ray.tmin, best);
+    }
+
+    if (ng.y <= 0x00FFFFFFu) {
+      if (sp == 0) break;
+      --sp;
+      ng = stk[sp * 64];
+    }
+  }
+  if (best.prim == 0xFFFFFFFFu) best.t = -1.0f;
+  return best;
+}
+
+}  // namespace ptd

@@ -1,0 +1,412 @@
+"""Scene ingestion for the hot path: the stand-in for FANCY's MeshImporter (PathTracer/PathTracer.cpp:115-132).
+
+* load_obj      minimal Wavefront OBJ/MTL reader producing the importer's output contract: per (group, material)
+                one mesh with interleaved {pos f3, normal f3, uv f2} vertices (PathTracer.cpp:116-120), one instance
+                per mesh with identity transform, materials {emission, colour}.
+* cornell_box   the reference's default scene (resources/models/CornellBox.obj) from a committed data fixture.
+* atrium / street / courtyard
+                deterministic procedural stand-ins for Sponza / Bistro / San Miguel (BASELINE.json configs 2-5): the
+                real assets are neither in the reference (.gitignore:45-46) nor available offline. Triangle counts are
+                exact; all randomness is an integer hash of the seed.
+"""
+import json
+import os
+
+import numpy as np
+
+from . import api
+from .context import SceneData
+
+_ASSETS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "assets")
+
+
+# ----------------------------------------------------------------------------------------------- OBJ / MTL
+def _parse_mtl(path):
+    mats, cur = {}, None
+    if not os.path.exists(path):
+        return mats
+    with open(path) as f:
+        for line in f:
+            t = line.split()
+            if not t or t[0].startswith("#"):
+                continue
+            if t[0] == "newmtl":
+                cur = t[1]
+                mats[cur] = {"Kd": (1.0, 1.0, 1.0), "Ke": (0.0, 0.0, 0.0)}
+            elif cur and t[0] in ("Kd", "Ke") and len(t) >= 4:
+                mats[cur][t[0]] = tuple(float(x) for x in t[1:4])
+    return mats
+
+
+def load_obj(path):
+    """One mesh per (o/g group, usemtl) run in file order — the order Assimp's OBJ importer yields and the reference
+    relies on (the Cornell light must be instance 4, PathTracer.h:125)."""
+    pos, nrm, tex = [], [], []
+    groups = []  # (name, material, [faces]) ; face = list of (vi, ti, ni)
+    mtl = {}
+    cur = None
+    cur_name, cur_mat = "default", None
+    with open(path) as f:
+        for line in f:
+            t = line.split()
+            if not t or t[0].startswith("#"):
+                continue
+            if t[0] == "v":
+                pos.append([float(x) for x in t[1:4]])
+            elif t[0] == "vn":
+                nrm.append([float(x) for x in t[1:4]])
+            elif t[0] == "vt":
+                tex.append([float(x) for x in t[1:3]])
+            elif t[0] == "mtllib":
+                mtl.update(_parse_mtl(os.path.join(os.path.dirname(path), t[1])))
+            elif t[0] in ("o", "g"):
+                cur_name = t[1] if len(t) > 1 else "default"
+                cur = None
+            elif t[0] == "usemtl":
+                cur_mat = t[1]
+                cur = None
+            elif t[0] == "f":
+                if cur is None:
+                    cur = (cur_name, cur_mat, [])
+                    groups.append(cur)
+                corners = []
+                for c in t[1:]:
+                    p = (c.split("/") + ["", ""])[:3]
+                    vi = int(p[0]); ti = int(p[1]) if p[1] else 0; ni = int(p[2]) if p[2] else 0
+                    corners.append((vi - 1 if vi > 0 else len(pos) + vi,
+                                    (ti - 1 if ti > 0 else len(tex) + ti) if ti else -1,
+                                    (ni - 1 if ni > 0 else len(nrm) + ni) if ni else -1))
+                for k in range(1, len(corners) - 1):  # fan triangulation
+                    cur[2].append((corners[0], corners[k], corners[k + 1]))
+    mat_names = list(mtl.keys())
+    for _, m, _ in groups:
+        if m is not None and m not in mat_names:
+            mat_names.append(m)
+            mtl[m] = {"Kd": (1.0, 1.0, 1.0), "Ke": (0.0, 0.0, 0.0)}
+    if not mat_names:
+        mat_names = ["default"]
+        mtl["default"] = {"Kd": (1.0, 1.0, 1.0), "Ke": (0.0, 0.0, 0.0)}
+    meshes, instances = [], []
+    for name, m, faces in groups:
+        vmap, verts, idx = {}, [], []
+        for tri in faces:
+            for key in tri:
+                if key not in vmap:
+                    vmap[key] = len(verts)
+                    p = pos[key[0]]
+                    uv = tex[key[1]] if key[1] >= 0 else [0.0, 0.0]
+                    n = nrm[key[2]] if key[2] >= 0 else None
+                    verts.append((p, n, uv, tri))
+                idx.append(vmap[key])
+        v = np.zeros(len(verts), dtype=api.VERTEX_DTYPE)
+        for i, (p, n, uv, tri) in enumerate(verts):
+            if n is None:  # no normal in the file: face normal
+                a, b, c = (np.array(pos[k[0]]) for k in tri)
+                n = np.cross(b - a, c - a)
+                n = n / max(np.linalg.norm(n), 1e-30)
+            v[i] = (p, n, uv)
+        meshes.append((v, np.array(idx, dtype=np.uint32)))
+        instances.append((len(meshes) - 1, mat_names.index(m) if m in mat_names else 0, None))
+    materials = [(mtl[n]["Ke"], tuple(mtl[n]["Kd"]) + (1.0,)) for n in mat_names]
+    return SceneData(meshes, instances, materials, name=os.path.basename(path))
+
+
+def scene_to_json(scene, path):
+    d = {"name": scene.name,
+         "meshes": [{"pos": v["pos"].tolist(), "normal": v["normal"].tolist(), "uv": v["uv"].tolist(),
+                     "indices": i.tolist()} for v, i in scene.meshes],
+         "instances": [[m, mat, None if t is None else t.tolist()] for m, mat, t in scene.instances],
+         "materials": [[list(e), list(c)] for e, c in scene.materials]}
+    with open(path, "w") as f:
+        json.dump(d, f, separators=(",", ":"))
+
+
+def scene_from_json(path):
+    with open(path) as f:
+        d = json.load(f)
+    meshes = []
+    for m in d["meshes"]:
+        v = np.zeros(len(m["pos"]), dtype=api.VERTEX_DTYPE)
+        v["pos"] = np.array(m["pos"], dtype=np.float32).reshape(-1, 3)
+        v["normal"] = np.array(m["normal"], dtype=np.float32).reshape(-1, 3)
+        v["uv"] = np.array(m["uv"], dtype=np.float32).reshape(-1, 2)
+        meshes.append((v, np.array(m["indices"], dtype=np.uint32)))
+    return SceneData(meshes, [tuple(i) for i in d["instances"]], [tuple(m) for m in d["materials"]], name=d.get("name", ""))
+
+
+def cornell_box():
+    """resources/models/CornellBox.obj as data (36 triangles, 6 mesh groups, light = instance 4).
+    Camera of the reference: position (1,102,-30), identity orientation (PathTracer.cpp:40,134-136)."""
+    return scene_from_json(os.path.join(_ASSETS, "cornell_box.json"))
+
+
+CORNELL_CAM_POS = (1.0, 102.0, -30.0)
+
+
+# ----------------------------------------------------------------------------------------------- procedural helpers
+def _hash_u32(x):
+    x = np.asarray(x, dtype=np.uint64) & 0xFFFFFFFF
+    x = (x ^ (x >> 16)) * 0x7FEB352D & 0xFFFFFFFF
+    x = (x ^ (x >> 15)) * 0x846CA68B & 0xFFFFFFFF
+    return (x ^ (x >> 16)).astype(np.uint64)
+
+
+def _rand01(seed, *idx):
+    h = np.uint64(seed) * np.uint64(0x9E3779B1) & np.uint64(0xFFFFFFFF)
+    for i in idx:
+        h = _hash_u32(h ^ (np.asarray(i, dtype=np.uint64) * np.uint64(0x85EBCA6B) & np.uint64(0xFFFFFFFF)))
+    return (h >> np.uint64(8)).astype(np.float64) / float(1 << 24)
+
+
+def _value_noise(seed, u, v, freq):
+    x, y = u * freq, v * freq
+    x0, y0 = np.floor(x).astype(np.int64), np.floor(y).astype(np.int64)
+    fx, fy = x - x0, y - y0
+    sx, sy = fx * fx * (3 - 2 * fx), fy * fy * (3 - 2 * fy)
+    def c(ix, iy):
+        return _rand01(seed, ix & 0xFFFF, iy & 0xFFFF)
+    top = c(x0, y0) * (1 - sx) + c(x0 + 1, y0) * sx
+    bot = c(x0, y0 + 1) * (1 - sx) + c(x0 + 1, y0 + 1) * sx
+    return top * (1 - sy) + bot * sy - 0.5
+
+
+def _grid_mesh(fn, nu, nv):
+    """Mesh of nu x nv quads over (u,v) in [0,1]^2; fn(u,v) -> (..., 3). Normals from the grid's own tangents."""
+    u, v = np.meshgrid(np.linspace(0.0, 1.0, nu + 1), np.linspace(0.0, 1.0, nv + 1), indexing="xy")
+    P = fn(u, v)                                     # (nv+1, nu+1, 3)
+    du = np.gradient(P, axis=1)
+    dv = np.gradient(P, axis=0)
+    N = np.cross(du, dv)
+    N /= np.maximum(np.linalg.norm(N, axis=-1, keepdims=True), 1e-30)
+    verts = np.zeros((nv + 1) * (nu + 1), dtype=api.VERTEX_DTYPE)
+    verts["pos"] = P.reshape(-1, 3).astype(np.float32)
+    verts["normal"] = N.reshape(-1, 3).astype(np.float32)
+    verts["uv"] = np.stack([u, v], axis=-1).reshape(-1, 2).astype(np.float32)
+    i, j = np.meshgrid(np.arange(nu), np.arange(nv), indexing="xy")
+    a = (j * (nu + 1) + i).reshape(-1)
+    b, c, d = a + 1, a + (nu + 1), a + (nu + 1) + 1
+    idx = np.stack([a, b, d, a, d, c], axis=-1).reshape(-1).astype(np.uint32)
+    return verts, idx
+
+
+def _merge(parts):
+    vs, is_, off = [], [], 0
+    for v, i in parts:
+        vs.append(v)
+        is_.append(i + np.uint32(off))
+        off += len(v)
+    return np.concatenate(vs), np.concatenate(is_)
+
+
+def _palette(seed, n):
+    """n untextured materials: albedo per channel uniform in [0.2,0.8] (quantised to unorm8 at upload), no emitters."""
+    mats = []
+    for k in range(n):
+        rgb = [0.2 + 0.6 * float(_rand01(seed, 1000 + k, c)) for c in range(3)]
+        mats.append(((0.0, 0.0, 0.0), (rgb[0], rgb[1], rgb[2], 1.0)))
+    return mats
+
+
+def _cylinder(cx, cz, y0, y1, r, seg, rings, seed):
+    def fn(u, v):
+        ang = 2 * np.pi * u
+        rr = r * (1.0 + 0.06 * np.cos(12 * ang) + 0.04 * _value_noise(seed, u * 4, v * 4, 8.0))   # fluted shaft
+        return np.stack([cx + rr * np.cos(ang), y0 + (y1 - y0) * v, cz + rr * np.sin(ang)], axis=-1)
+    return _grid_mesh(fn, seg, rings)
+
+
+def _arch(x0, x1, y, z, thick, depth, seg):
+    """Half-ring with rectangular cross-section spanning x0..x1, springing at height y."""
+    cx, R = 0.5 * (x0 + x1), 0.5 * (x1 - x0)
+    parts = []
+    for (ra, rb, za, zb) in ((R - thick, R - thick, z - depth, z + depth), (R, R, z - depth, z + depth),
+                             (R - thick, R, z - depth, z - depth), (R - thick, R, z + depth, z + depth)):
+        def fn(u, v, ra=ra, rb=rb, za=za, zb=zb):
+            ang = np.pi * u
+            rr = ra + (rb - ra) * v
+            return np.stack([cx - rr * np.cos(ang), y + rr * np.sin(ang), za + (zb - za) * v], axis=-1)
+        parts.append(_grid_mesh(fn, seg, 1))
+    return _merge(parts)
+
+
+def atrium(seed=1):
+    """"Sponza-class" stand-in (BASELINE.json config 2/3): open-top courtyard 40 x 16 x 20 m, two storeys of 12 x 4
+    fluted columns with arches, gallery slabs, displaced floor and walls, hanging cloth. Exactly 262,144 triangles,
+    24 materials, no emitters (lit by the sky through the open top)."""
+    meshes, instances = [], []
+    def add(mesh, mat):
+        meshes.append(mesh)
+        instances.append((len(meshes) - 1, mat % 24, None))
+
+    amp = 0.02
+    # floor: 232 x 96 quads
+    add(_grid_mesh(lambda u, v: np.stack([-20 + 40 * u, amp * _value_noise(seed, u, v, 64.0) * 2, -10 + 20 * v], axis=-1), 232, 96), 0)
+    # long walls (z = -10, +10): 160 x 64 quads each; short walls (x = -20, +20): 80 x 64
+    for k, zz in enumerate((-10.0, 10.0)):
+        add(_grid_mesh(lambda u, v, zz=zz, k=k: np.stack([-20 + 40 * u, 16 * v, zz + amp * 2 * _value_noise(seed + 10 + k, u, v, 48.0) + 0 * u], axis=-1), 160, 64), 1 + k)
+    for k, xx in enumerate((-20.0, 20.0)):
+        add(_grid_mesh(lambda u, v, xx=xx, k=k: np.stack([xx + amp * 2 * _value_noise(seed + 20 + k, u, v, 48.0) + 0 * u, 16 * v, -10 + 20 * u], axis=-1), 80, 64), 3 + k)
+    # gallery slabs at y = 8 along both long walls: top and bottom faces, 128 x 16 quads each
+    for k, (za, zb) in enumerate(((-10.0, -5.0), (5.0, 10.0))):
+        top = _grid_mesh(lambda u, v, za=za, zb=zb: np.stack([-20 + 40 * u, 8.0 + amp * _value_noise(seed + 30 + k, u, v, 64.0), za + (zb - za) * v], axis=-1), 128, 16)
+        bot = _grid_mesh(lambda u, v, za=za, zb=zb: np.stack([-20 + 40 * u, 7.6 + 0 * u, za + (zb - za) * v], axis=-1), 128, 16)
+        add(_merge([top, bot]), 5 + k)
+    # columns: 2 storeys x 12 x 4, 32 segments x 16 rings
+    xs = np.linspace(-17.5, 17.5, 12)
+    zs = (-8.0, -5.0, 5.0, 8.0)
+    for s, (y0, y1) in enumerate(((0.0, 6.2), (8.0, 14.2))):
+        for iz, z in enumerate(zs):
+            for ix, x in enumerate(xs):
+                add(_cylinder(x, z, y0, y1, 0.35, 32, 16, seed + 100 + s * 48 + iz * 12 + ix), 7 + (ix + iz + s) % 5)
+    # arches between neighbouring columns of every row: 24 segments
+    for s, y in enumerate((6.2, 14.2)):
+        for iz, z in enumerate(zs):
+            for ix in range(11):
+                add(_arch(xs[ix], xs[ix + 1], y, z, 0.35, 0.3, 24), 12 + (ix + s) % 4)
+    # hanging cloth: 8 curved sheets, 48 x 32 quads
+    for k in range(8):
+        x0 = -16.0 + 4.5 * k
+        def fn(u, v, x0=x0, k=k):
+            sag = 1.2 * np.sin(np.pi * u) * (0.6 + 0.4 * np.cos(2 * np.pi * v))
+            return np.stack([x0 + 2.5 * v + 0.15 * _value_noise(seed + 200 + k, u, v, 6.0), 13.5 - sag, -4.5 + 9.0 * u], axis=-1)
+        add(_grid_mesh(fn, 48, 32), 16 + k)
+    scene = SceneData(meshes, instances, _palette(seed, 24), name=f"atrium(seed={seed})")
+    assert scene.num_triangles == 262144, scene.num_triangles
+    return scene
+
+
+ATRIUM_CAM = {"eye": (-17.0, 1.7, 0.6), "target": (10.0, 5.5, -0.8)}
+
+
+def _building_block(seed, x0, x1, z0, z1, height, nu, nv, amp=0.08):
+    """Four displaced facade grids + a roof."""
+    parts = []
+    faces = (((x0, z0), (x1, z0)), ((x1, z0), (x1, z1)), ((x1, z1), (x0, z1)), ((x0, z1), (x0, z0)))
+    for k, ((ax, az), (bx, bz)) in enumerate(faces):
+        nx, nz = (bz - az), -(bx - ax)
+        ln = max(np.hypot(nx, nz), 1e-9)
+        nx, nz = nx / ln, nz / ln
+        def fn(u, v, ax=ax, az=az, bx=bx, bz=bz, nx=nx, nz=nz, k=k):
+            # window-like relief: periodic recess + noise
+            relief = amp * (np.sign(np.sin(2 * np.pi * 6 * u) * np.sin(2 * np.pi * 5 * v)) * 0.5 + _value_noise(seed + k, u, v, 24.0))
+            return np.stack([ax + (bx - ax) * u + nx * relief, height * v, az + (bz - az) * u + nz * relief], axis=-1)
+        parts.append(_grid_mesh(fn, nu, nv))
+    parts.append(_grid_mesh(lambda u, v: np.stack([x0 + (x1 - x0) * u, height + 0.3 * _value_noise(seed + 9, u, v, 8.0), z0 + (z1 - z0) * v], axis=-1), nu // 2, nu // 2))
+    return _merge(parts)
+
+
+def _filler_grid(seed, n_tris, x0, x1, z0, z1, y):
+    """A displaced ground grid with exactly n_tris triangles (n_tris even)."""
+    assert n_tris % 2 == 0 and n_tris > 0
+    q = n_tris // 2
+    nv = int(np.sqrt(q))
+    while q % nv:
+        nv -= 1
+    nu = q // nv
+    return _grid_mesh(lambda u, v: np.stack([x0 + (x1 - x0) * u, y + 0.03 * _value_noise(seed, u, v, 96.0), z0 + (z1 - z0) * v], axis=-1), nu, nv)
+
+
+def street(seed=2, target_tris=3145728):
+    """"Bistro-class" stand-in (config 4): a street canyon of relief facades, lamp posts, awnings and a displaced
+    ground, exactly 3,145,728 triangles, 64 materials."""
+    meshes, instances = [], []
+    def add(mesh, mat):
+        meshes.append(mesh)
+        instances.append((len(meshes) - 1, mat % 64, None))
+    total = 0
+    k = 0
+    for side, z0, z1 in ((0, 8.0, 28.0), (1, -28.0, -8.0)):
+        x = -120.0
+        while x < 120.0:
+            wdt = 14.0 + 10.0 * float(_rand01(seed, 10, k))
+            hgt = 10.0 + 18.0 * float(_rand01(seed, 11, k))
+            m = _building_block(seed + 50 + k, x, x + wdt, z0, z1, hgt, 192, 160)
+            add(m, k)
+            total += len(m[1]) // 3
+            x += wdt + 1.0
+            k += 1
+    for j in range(40):  # lamp posts
+        m = _cylinder(-115.0 + 6.0 * j, 6.5 if j % 2 else -6.5, 0.0, 5.0, 0.08, 24, 32, seed + 500 + j)
+        add(m, 40 + j % 8)
+        total += len(m[1]) // 3
+    for j in range(24):  # awnings (cloth-like)
+        x0 = -110.0 + 9.0 * j
+        zs = 8.0 if j % 2 else -8.0
+        m = _grid_mesh(lambda u, v, x0=x0, zs=zs, j=j: np.stack([x0 + 4.0 * u, 3.2 - 0.5 * v + 0.1 * np.sin(8 * np.pi * u), zs - np.sign(zs) * 2.0 * v + 0.05 * _value_noise(seed + 600 + j, u, v, 8.0)], axis=-1), 64, 32)
+        add(m, 48 + j % 8)
+        total += len(m[1]) // 3
+    rest = target_tris - total
+    assert rest > 0 and rest % 2 == 0, (total, rest)
+    add(_filler_grid(seed + 700, rest, -125.0, 125.0, -30.0, 30.0, 0.0), 60)
+    scene = SceneData(meshes, instances, _palette(seed, 64), name=f"street(seed={seed})")
+    assert scene.num_triangles == target_tris, scene.num_triangles
+    return scene
+
+
+STREET_CAM = {"eye": (-100.0, 1.7, 0.5), "target": (60.0, 9.0, -1.0)}
+
+
+def courtyard(seed=3, target_tris=10485760):
+    """"San-Miguel-class" stand-in (config 5): an arcaded courtyard with many small leaf-like quads (high depth
+    complexity). Exactly 10,485,760 triangles."""
+    meshes, instances = [], []
+    def add(mesh, mat):
+        meshes.append(mesh)
+        instances.append((len(meshes) - 1, mat % 64, None))
+    total = 0
+    # surrounding arcade buildings
+    blocks = ((-40.0, 40.0, 30.0, 45.0), (-40.0, 40.0, -45.0, -30.0), (-55.0, -40.0, -45.0, 45.0), (40.0, 55.0, -45.0, 45.0))
+    for k, (x0, x1, z0, z1) in enumerate(blocks):
+        m = _building_block(seed + 10 + k, x0, x1, z0, z1, 14.0, 512, 256, amp=0.12)
+        add(m, k)
+        total += len(m[1]) // 3
+    # trees: trunk + a cloud of small leaf quads (2 triangles each)
+    n_trees, leaves_per_tree = 24, 120000
+    for t in range(n_trees):
+        cx = -30.0 + 60.0 * float(_rand01(seed, 20, t))
+        cz = -22.0 + 44.0 * float(_rand01(seed, 21, t))
+        trunk = _cylinder(cx, cz, 0.0, 5.0, 0.25, 24, 16, seed + 100 + t)
+        add(trunk, 8 + t % 4)
+        total += len(trunk[1]) // 3
+        i = np.arange(leaves_per_tree)
+        r = 3.2 * np.cbrt(_rand01(seed + t, 30, i))
+        th = 2 * np.pi * _rand01(seed + t, 31, i)
+        ph = np.arccos(1 - 2 * _rand01(seed + t, 32, i))
+        c = np.stack([cx + r * np.sin(ph) * np.cos(th), 6.5 + 0.8 * r * np.cos(ph), cz + r * np.sin(ph) * np.sin(th)], axis=-1)
+        a = 2 * np.pi * _rand01(seed + t, 33, i)
+        b = np.pi * _rand01(seed + t, 34, i)
+        e1 = 0.09 * np.stack([np.cos(a) * np.sin(b), np.cos(b), np.sin(a) * np.sin(b)], axis=-1)
+        e2 = 0.05 * np.cross(e1 / 0.09, np.stack([np.sin(a), 0 * a, -np.cos(a)], axis=-1))
+        nrm = np.cross(e1, e2)
+        nrm /= np.maximum(np.linalg.norm(nrm, axis=-1, keepdims=True), 1e-30)
+        v = np.zeros(4 * leaves_per_tree, dtype=api.VERTEX_DTYPE)
+        v["pos"] = np.stack([c - e1 - e2, c + e1 - e2, c + e1 + e2, c - e1 + e2], axis=1).reshape(-1, 3).astype(np.float32)
+        v["normal"] = np.repeat(nrm, 4, axis=0).astype(np.float32)
+        base = (4 * i).astype(np.uint32)
+        idx = np.stack([base, base + 1, base + 2, base, base + 2, base + 3], axis=-1).reshape(-1).astype(np.uint32)
+        add((v, idx), 12 + t % 8)
+        total += 2 * leaves_per_tree
+    rest = target_tris - total
+    assert rest > 0 and rest % 2 == 0, (total, rest)
+    add(_filler_grid(seed + 900, rest, -40.0, 40.0, -30.0, 30.0, 0.0), 30)
+    scene = SceneData(meshes, instances, _palette(seed, 64), name=f"courtyard(seed={seed})")
+    assert scene.num_triangles == target_tris, scene.num_triangles
+    return scene
+
+
+COURTYARD_CAM = {"eye": (-34.0, 1.7, -24.0), "target": (10.0, 6.0, 8.0)}
+
+
+def random_triangle_soup(seed, n, extent=10.0, size=1.0):
+    """n random triangles in a cube — intersection-parity tests."""
+    i = np.arange(n)
+    c = np.stack([_rand01(seed, 1, i), _rand01(seed, 2, i), _rand01(seed, 3, i)], axis=-1) * extent
+    e = (np.stack([_rand01(seed, 4 + k, i) for k in range(9)], axis=-1).reshape(n, 3, 3) - 0.5) * size
+    P = (c[:, None, :] + e).astype(np.float32)
+    v = np.zeros(3 * n, dtype=api.VERTEX_DTYPE)
+    v["pos"] = P.reshape(-1, 3)
+    nrm = np.cross(P[:, 1] - P[:, 0], P[:, 2] - P[:, 0])
+    nrm /= np.maximum(np.linalg.norm(nrm, axis=-1, keepdims=True), 1e-30)
+    v["normal"] = np.repeat(nrm, 3, axis=0)
+    idx = np.arange(3 * n, dtype=np.uint32)
+    return SceneData([(v, idx)], [(0, 0, None)], [((0.0, 0.0, 0.0), (0.7, 0.7, 0.7, 1.0))], name=f"soup({seed},{n})")
