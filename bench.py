@@ -1,0 +1,210 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the path-tracing hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...)
+
+Workload (BASELINE.json configs[1], "C2"): procedural Sponza-class atrium(seed=1), 262,144 triangles, 1920x1080,
+myMaxRecursionDepth 4 (<= 5 rays per sample), Sky.cpp atmosphere on. One STEP = one pass of the whole hot path
+(generate -> [extend -> shade] x 5 -> sky -> resolve) over one batch of --spp-per-step samples per pixel; scene, BVH and
+all queues are resident in HBM before the timed region. With N GPUs every rank renders the full frame for its own
+sample indices (weak scaling) and the timed region ends with one RCCL reduce of the accumulation targets.
+
+Prints ONE JSON line on rank 0: whole-job Mrays/s (+ Msamples/s), the extend kernel's roofline object and the CPU
+oracle baseline (bounded sample, rank 0 at N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+NODE_BYTES, TRI_BYTES, RAY_IO_BYTES = 80, 48, 48   # B_ray = 80*N_node + 48*N_tri + 48
+
+
+def make_workload(name):
+    from pathtracer_amd import scenes
+    if name == "atrium":
+        return scenes.atrium(1), scenes.ATRIUM_CAM, 4, "C2 atrium(seed=1) 262144 tris, sky on"
+    if name == "street":
+        return scenes.street(2), scenes.STREET_CAM, 8, "C4 street(seed=2) 3145728 tris, sky on"
+    if name == "courtyard":
+        return scenes.courtyard(3), scenes.COURTYARD_CAM, 16, "C5 courtyard(seed=3) 10485760 tris, sky on"
+    if name == "cornell":
+        return scenes.cornell_box(), None, 4, "C1 Cornell box 36 tris, sky off"
+    raise ValueError(name)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=6)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--spp-per-step", type=int, default=4)
+    ap.add_argument("--depth", type=int, default=-1, help="myMaxRecursionDepth (default: the workload's)")
+    ap.add_argument("--workload", default="atrium", choices=["atrium", "street", "courtyard", "cornell"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from pathtracer_amd import PathTracer, api
+    from pathtracer_amd import distributed as ptdist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    W, H, K, WU, SPP = args.width, args.height, args.steps, args.warmup, args.spp_per_step
+    scene, cam, depth, label = make_workload(args.workload)
+    if args.depth >= 0:
+        depth = args.depth
+
+    pt = PathTracer(local_rank, W, H)
+    pt.myHalfResRender = False
+    pt.UpdateOutputTexture()
+    from pathtracer_amd import scenes as _sc
+    if cam is None:
+        pt.LoadScene(scene, _sc.CORNELL_CAM_POS)
+        pt.mySampleSky = False
+        pt.mySkyFallbackIntensity = 0.0
+    else:
+        pt.LoadScene(scene, cam["eye"])
+        pt.myCamera.LookAt(cam["eye"], cam["target"])
+        pt.mySampleSky = True
+        pt.myLightInstanceIdx = -1
+        pt.mySky.mySunDir = np.array([0.3, 0.8, 0.52], dtype=np.float32) / np.float32(np.linalg.norm([0.3, 0.8, 0.52]))
+    pt.myMaxRecursionDepth = depth
+    ctx = pt.ctx
+    info = ctx.scene_info()
+    target = ptdist.bind_torch_target(ctx, W, H, dev)   # accumulation target RCCL can reduce in place
+    if pt.mySampleSky:
+        pt.mySky.ComputeTranmittanceLut()
+        pt._sky_dirty = False
+    consts = pt.BuildRtConsts()
+    ctx.set_option(api.PT_OPT_SAMPLES_PER_BATCH, SPP)
+
+    total_steps = WU + K
+    # this rank's sample indices: a contiguous block of (WU+K)*SPP samples
+    first0 = rank * total_steps * SPP
+
+    def step(i):
+        ctx.render(consts, W, H, first0 + i * SPP, SPP)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        ctx.synchronize()
+        torch.cuda.synchronize()
+
+    for i in range(WU):
+        step(i)
+    barrier()
+    ctx.stats_reset()
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(K):
+        step(WU + i)
+    ctx.synchronize()
+    if world > 1:   # the one exchange step of the job: sum of the per-GPU float targets onto rank 0
+        _, n_total = ptdist.reduce_sum_to_root(target, (WU + K) * SPP)
+    barrier()
+    t1 = time.perf_counter()
+    st = ctx.stats()
+    elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
+    counts = torch.tensor([st.rays, st.samples], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
+        dist.all_reduce(counts, op=dist.ReduceOp.SUM)
+    elapsed_s = float(elapsed.item())
+    rays_all, samples_all = float(counts[0].item()), float(counts[1].item())
+
+    roofline = None
+    if rank == 0 and not args.no_roofline:
+        # (1) algorithmic bytes: counting instantiation of the extend kernel on one step of the same workload
+        ctx.stats_reset()
+        ctx.set_option(api.PT_OPT_COUNT_TRAVERSAL, 1)
+        step(total_steps)
+        sc_ = ctx.stats()
+        ctx.set_option(api.PT_OPT_COUNT_TRAVERSAL, 0)
+        nodes_per_ray = sc_.nodes_visited / max(1, sc_.rays)
+        tris_per_ray = sc_.tris_tested / max(1, sc_.rays)
+        bytes_per_ray = NODE_BYTES * nodes_per_ray + TRI_BYTES * tris_per_ray + RAY_IO_BYTES
+        # (2) extend-kernel time: HIP events on the ctx stream around every extend launch, K more steps
+        ctx.stats_reset()
+        ctx.set_option(api.PT_OPT_TIME_KERNELS, 1)
+        for i in range(K):
+            step(total_steps + 1 + i)
+        se = ctx.stats()
+        ctx.set_option(api.PT_OPT_TIME_KERNELS, 0)
+        ext_s = se.extend_ms * 1e-3
+        achieved = bytes_per_ray * se.rays / max(ext_s, 1e-12) / 1e9
+        roofline = {
+            "bound": "hbm", "kernel": "k_extend", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+            "nodes_per_ray": round(nodes_per_ray, 3), "tris_per_ray": round(tris_per_ray, 3),
+            "bytes_per_ray": round(bytes_per_ray, 1),
+            "launches": int(se.extend_launches), "avg_launch_ms": round(se.extend_ms / max(1, se.extend_launches), 4),
+            "bytes_per_launch": round(bytes_per_ray * se.rays / max(1, se.extend_launches), 1),
+            "extend_share_of_render": round(se.extend_ms / max(se.render_ms, 1e-9), 4),
+            "extend_mrays_per_s": round(se.rays / max(ext_s, 1e-12) / 1e6, 2),
+        }
+
+    cpu_baseline = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from tests import oracle_lib
+        orc = oracle_lib.load()
+        oscene = orc.scene(scene)
+        lut = orc.transmittance_lut(pt.mySky.myAtmosphereParams) if pt.mySampleSky else None
+        # bounded sample: 1 spp of the same frame at 1/4 resolution per axis (same camera, same scene, same depth)
+        cw, ch = max(16, W // 4), max(16, H // 4)
+        c2 = pt.BuildRtConsts()
+        _, ostats, _ = oscene.render(c2, cw, ch, 0, 2, lut=lut)
+        sec = ostats["ns"] * 1e-9
+        cpu_baseline = {
+            "value": round(ostats["rays"] / sec / 1e6, 3), "unit": "Mrays/s", "cores": int(ostats["threads"]), "kind": "port",
+            "msamples_per_s": round(ostats["samples"] / sec / 1e6, 3),
+            "sample": f"2 spp of the same workload at {cw}x{ch} ({ostats['samples']} samples, {ostats['rays']} rays, {sec:.2f} s), "
+                      "oracle/libpt_oracle.so, OpenMP over rows",
+        }
+
+    if rank == 0:
+        out = {
+            "metric": "Mrays/s + Msamples/s at 1080p, 4 bounces, 1/2/4/8 MI355X",
+            "value": round(rays_all / elapsed_s / 1e6, 2),
+            "unit": "Mrays/s",
+            "msamples_per_s": round(samples_all / elapsed_s / 1e6, 2),
+            "n_gpus": world, "steps": K, "warmup": WU,
+            "ms_per_step": round(elapsed_s / K * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": label, "width": W, "height": H, "max_recursion_depth": depth, "spp_per_step": SPP,
+                       "triangles": int(info.num_triangles), "bvh_nodes": int(info.num_bvh_nodes),
+                       "bvh_mb": round(info.bvh_bytes / 1e6, 2), "bvh_build_ms": round(info.build_ms, 1),
+                       "rays_per_sample": round(rays_all / max(samples_all, 1), 3),
+                       "parallelism": f"sample-partition x{world}" if world > 1 else "single GPU"},
+            "roofline": roofline,
+            "cpu_baseline": cpu_baseline,
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
