@@ -130,7 +130,7 @@ static inline bool intersect_tri(const RayPre& r, const Tri& tri, uint32_t prim,
   const float rcpDet = 1.0f / det;
   const float t = T * rcpDet;
   if (!(t > tmin)) return false;
-  if (t < best.t || (t == best.t && prim < best.prim)) {
+  if (t < best.t || (t == best.t && best.prim != PT_MISS && prim < best.prim)) {  // t == tmax itself is NOT a hit
     best.t = t;
     best.u = V * rcpDet;
     best.v = W * rcpDet;

@@ -69,7 +69,7 @@ struct TriTester {
     const float t = T * rcpDet;
     if (!(t > tmin)) return;
     const uint32_t prim = q0.w;
-    if (t < best.t || (t == best.t && prim < best.prim)) {
+    if (t < best.t || (t == best.t && best.prim != 0xFFFFFFFFu && prim < best.prim)) {  // t == tmax itself is not a hit
       best.t = t;
       best.u = V * rcpDet;
       best.v = W * rcpDet;

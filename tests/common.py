@@ -1,0 +1,107 @@
+"""Shared helpers for the tests and the fixture generator (host-side only: no GPU, no oracle import)."""
+import math
+
+import numpy as np
+
+from pathtracer_amd import api, scenes
+from pathtracer_amd.pathtracer import Camera, SetupEarthAtmosphere
+
+
+def make_consts(cam, depth=4, sky=False, fallback=0.0, light_instance=4, light=100.0, phong=10.0,
+                sun_dir=(0.0, 1.0, 0.0), sun_ill=1000.0):
+    """RtConsts exactly as PathTracer::RenderRT fills them (PathTracer.cpp:689-768), without needing a GPU ctx."""
+    c = api.PtRtConsts()
+    v = cam.GetVerticesOnNearPlane()
+    api.fill3(c.myNearPlaneCorner, v[0])
+    c.myAoDistance = 1.0
+    api.fill3(c.myXAxis, v[1] - v[0])
+    api.fill3(c.myYAxis, v[3] - v[0])
+    api.fill3(c.myCameraPos, cam.myPosition)
+    c.myLightInstanceId = light_instance & 0xFFFFFFFF
+    c.myNumHaltonSamples = 8192
+    api.fill3(c.myLightEmission, (light,) * 3)
+    c.mySampleSky = 1 if sky else 0
+    api.fill3(c.mySkyFallbackEmission, (fallback,) * 3)
+    c.myPhongSpecularPower = phong
+    c.myMaxRecursionDepth = depth
+    sc = c.mySkyConsts
+    sc.myAtmosphere = SetupEarthAtmosphere()
+    s = np.asarray(sun_dir, dtype=np.float64)
+    s = (s / np.linalg.norm(s)).astype(np.float32)
+    api.fill3(sc.mySunDirection, s)
+    api.fill3(sc.mySunIlluminance, (sun_ill,) * 3)
+    sc.myRayMarchMinMaxSPP[0], sc.myRayMarchMinMaxSPP[1] = 4.0, 14.0
+    return c
+
+
+def cornell_camera(w, h):
+    cam = Camera()
+    cam.myPosition = np.array(scenes.CORNELL_CAM_POS, dtype=np.float32)
+    cam.myWidth, cam.myHeight = float(w), float(h)
+    return cam
+
+
+def cornell_consts(w, h, depth=4, sky=False, fallback=0.0):
+    """BASELINE config C1: camera (1,102,-30), +Z forward, vfov 60, light instance 4 emission 100, Phong power 10."""
+    return make_consts(cornell_camera(w, h), depth=depth, sky=sky, fallback=fallback)
+
+
+def lookat_consts(w, h, cam_spec, depth=4, sky=True, sun_dir=(0.3, 0.8, 0.52)):
+    cam = Camera()
+    cam.myWidth, cam.myHeight = float(w), float(h)
+    cam.LookAt(cam_spec["eye"], cam_spec["target"])
+    return make_consts(cam, depth=depth, sky=sky, light_instance=-1, sun_dir=sun_dir)
+
+
+def _unit(rng, n):
+    v = rng.normal(size=(n, 3))
+    return v / np.linalg.norm(v, axis=1, keepdims=True)
+
+
+def function_inputs(fn, n, seed):
+    """Seeded input rows for pt_debug_eval / orc_eval (row layouts: include/pt_api.h PT_FN_*)."""
+    rng = np.random.default_rng(seed)
+    if fn == api.PT_FN_RAND01:
+        return np.stack([rng.integers(0, 4096, n), rng.integers(0, 4096, n), rng.integers(0, 1 << 20, n),
+                         np.full(n, 8)], axis=1).astype(np.float32)
+    if fn == api.PT_FN_FRESNEL:
+        N = _unit(rng, n) * rng.uniform(0.8, 1.0, (n, 1))   # interpolated normals are not unit length
+        return np.concatenate([N, _unit(rng, n)], axis=1).astype(np.float32)
+    if fn == api.PT_FN_SPEC_PROB:
+        return np.concatenate([rng.uniform(0, 1, (n, 3)), rng.uniform(0, 1, (n, 1))], axis=1).astype(np.float32)
+    if fn == api.PT_FN_SAMPLE_PHONG:
+        return np.concatenate([rng.uniform(0, 1, (n, 2)), _unit(rng, n), rng.uniform(1, 64, (n, 1))], axis=1).astype(np.float32)
+    if fn == api.PT_FN_EVAL_PHONG:
+        return np.concatenate([_unit(rng, n), _unit(rng, n), _unit(rng, n), rng.uniform(1, 64, (n, 1))], axis=1).astype(np.float32)
+    if fn == api.PT_FN_COS_HEMISPHERE:
+        return np.concatenate([rng.uniform(0, 1, (n, 2)), _unit(rng, n)], axis=1).astype(np.float32)
+    if fn == api.PT_FN_LAMBERT:
+        return np.concatenate([rng.uniform(0, 1, (n, 3)), _unit(rng, n), _unit(rng, n)], axis=1).astype(np.float32)
+    if fn == api.PT_FN_SKY:
+        pos = np.stack([rng.uniform(-50, 50, n), rng.uniform(0, 2000, n), rng.uniform(-50, 50, n)], axis=1)
+        d = _unit(rng, n)
+        d[:, 1] = np.abs(d[:, 1]) * np.where(rng.uniform(0, 1, n) < 0.85, 1.0, -1.0)   # mostly upward
+        d /= np.linalg.norm(d, axis=1, keepdims=True)
+        return np.concatenate([pos, d], axis=1).astype(np.float32)
+    if fn == api.PT_FN_PRIMARY_RAY:
+        return np.stack([rng.uniform(0, 64, n), rng.uniform(0, 64, n), np.full(n, 64), np.full(n, 64)], axis=1).astype(np.float32)
+    raise ValueError(fn)
+
+
+def rel_mse(img, ref):
+    img = np.asarray(img, dtype=np.float64)[..., :3]
+    ref = np.asarray(ref, dtype=np.float64)[..., :3]
+    return float(((img - ref) ** 2).mean() / max((ref ** 2).mean(), 1e-30))
+
+
+def random_rays(seed, n, lo, hi, tmin=0.0, tmax=10000.0):
+    """Incoherent rays: origins uniform in the padded box, uniform directions."""
+    rng = np.random.default_rng(seed)
+    lo, hi = np.asarray(lo, dtype=np.float64), np.asarray(hi, dtype=np.float64)
+    ext = hi - lo
+    rays = np.zeros(n, dtype=api.RAY_DTYPE)
+    rays["origin"] = (lo - 0.1 * ext + rng.uniform(0, 1, (n, 3)) * 1.2 * ext).astype(np.float32)
+    rays["dir"] = _unit(rng, n).astype(np.float32)
+    rays["tmin"] = tmin
+    rays["tmax"] = tmax
+    return rays

@@ -1,0 +1,191 @@
+"""CPU tests of the host side: C-ABI library loads and exports every declared symbol, struct layouts match the
+reference's constant buffer, camera / OBJ reader / scene generators / sample partitioning, and the N>1 reduce path
+under gloo with world_size 2 (the per-rank 'renderer' is the CPU oracle, standing in for a GPU)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from pathtracer_amd import api, scenes
+from pathtracer_amd.context import SceneData, encode_unorm_rgba, pack_scene
+from pathtracer_amd.distributed import partition_samples
+from pathtracer_amd.pathtracer import Camera, SetupEarthAtmosphere
+from tests.common import cornell_camera, cornell_consts
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    lib = api.load_library()
+    header = open(os.path.join(ROOT, "include", "pt_api.h")).read()
+    declared = set(re.findall(r"^(?:int|const char\*)\s+(pt_[a-z_]+)\s*\(", header, flags=re.M))
+    assert declared, "no declarations parsed from pt_api.h"
+    assert declared == set(api.SYMBOLS), declared ^ set(api.SYMBOLS)
+    for name in declared:
+        assert getattr(lib, name) is not None
+
+
+def test_rtconsts_layout_matches_reference_offsets():
+    """Byte offsets of RtConsts (PathTracer.cpp:709-740 == raytracing/Common.hlsl:24-55), SURVEY §8 a2."""
+    off = {f[0]: getattr(api.PtRtConsts, f[0]).offset for f in api.PtRtConsts._fields_}
+    want = {"myNearPlaneCorner": 0, "myAoDistance": 12, "myXAxis": 16, "myOutTexIndex": 28, "myYAxis": 32,
+            "myAsIndex": 44, "myCameraPos": 48, "myInstanceDataBufferIndex": 60, "myMaterialDataBufferIndex": 64,
+            "mySampleBufferIndex": 68, "myFrameRandomSeed": 72, "myNumAccumulationFrames": 76,
+            "myLinearClampSamplerIndex": 80, "myMaxRecursionDepth": 84, "myLightInstanceId": 88,
+            "myNumHaltonSamples": 92, "myLightEmission": 96, "mySampleSky": 108, "mySkyFallbackEmission": 112,
+            "myPhongSpecularPower": 124, "mySkyConsts": 128}
+    assert off == want
+    sk = {f[0]: getattr(api.PtSkyConstants, f[0]).offset for f in api.PtSkyConstants._fields_}
+    assert sk["mySunDirection"] == 112 and sk["myTransmissionLutTexIdx"] == 124 and sk["mySunIlluminance"] == 128
+    assert sk["myRayMarchMinMaxSPP"] == 144 and C.sizeof(api.PtRtConsts) == 288 and C.sizeof(api.PtAtmosphere) == 112
+    assert C.sizeof(api.PtMaterial) == 16 and C.sizeof(api.PtInstanceDesc) == 72
+
+
+def test_no_device_error_is_reported_not_hidden():
+    """Without a GPU the product must fail loudly (there is no CPU fallback)."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    lib = api.load_library()
+    h = C.c_void_p()
+    rc = lib.pt_create(0, C.byref(h))
+    assert rc == api.PT_ERR_NO_DEVICE and not h.value
+    assert b"no HIP device" in lib.pt_last_error(None)
+    from pathtracer_amd import Context
+    with pytest.raises(api.PtError):
+        Context(0)
+    assert lib.pt_render(None, None, 1, 1, 0, 1) == api.PT_ERR_INVALID_ARG
+    assert lib.pt_destroy(None) == api.PT_ERR_INVALID_ARG
+
+
+def test_camera_near_plane_and_primary_ray_geometry():
+    cam = cornell_camera(512, 512)
+    v = cam.GetVerticesOnNearPlane()
+    half = np.float32(np.tan(np.radians(30.0)))
+    np.testing.assert_allclose(v[0], [1 - half, 102 - half, -29], rtol=1e-6)
+    np.testing.assert_allclose(v[1] - v[0], [2 * half, 0, 0], atol=2e-5)   # fp32 ulp at |y|~102 is 7.6e-6
+    np.testing.assert_allclose(v[3] - v[0], [0, 2 * half, 0], atol=2e-5)
+    cam2 = Camera()
+    cam2.myWidth, cam2.myHeight = 1920.0, 1080.0
+    cam2.LookAt((0, 0, 0), (0, 0, 5))
+    w = cam2.GetVerticesOnNearPlane()
+    np.testing.assert_allclose((w[1] - w[0])[0] / (w[3] - w[0])[1], 16 / 9, rtol=1e-6)
+    c = cornell_consts(64, 64)
+    assert tuple(c.myCameraPos) == (1.0, 102.0, -30.0) and c.myMaxRecursionDepth == 4 and c.myLightInstanceId == 4
+    assert tuple(c.myLightEmission) == (100.0, 100.0, 100.0) and c.myPhongSpecularPower == 10.0
+    assert tuple(c.mySkyConsts.myRayMarchMinMaxSPP) == (4.0, 14.0)
+
+
+def test_cornell_fixture_matches_reference_scene_shape():
+    sc = scenes.cornell_box()
+    assert sc.num_triangles == 36 and len(sc.meshes) == 6 and len(sc.materials) == 5
+    assert [len(i) // 3 for _, i in sc.meshes] == [6, 2, 2, 12, 2, 12]     # light = instance 4 (PathTracer.h:125)
+    light = sc.meshes[4][0]
+    np.testing.assert_allclose(light["pos"][:, 1], 107.944885, rtol=1e-7)
+    np.testing.assert_allclose(light["normal"], [[0, -1, 0]] * len(light), atol=1e-6)
+    allp = np.concatenate([v["pos"] for v, _ in sc.meshes])
+    np.testing.assert_allclose(allp.min(0), [-4.732368, 97.092285, -6.766661], rtol=1e-6)
+    cols = sorted(encode_unorm_rgba(c) & 0xFFFFFF for _, c in sc.materials)
+    assert 0x000080 in cols and 0x008000 in cols            # red and green walls, Kd 0.5 -> 128
+
+
+def test_obj_reader_roundtrip(tmp_path):
+    (tmp_path / "m.mtl").write_text("newmtl a\nKd 0.2 0.4 0.6\nKe 1 2 3\nnewmtl b\nKd 1 1 1\n")
+    (tmp_path / "m.obj").write_text(
+        "mtllib m.mtl\no one\nv 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nvn 0 0 1\nvt 0 0\nvt 1 0\nvt 1 1\nvt 0 1\n"
+        "usemtl a\nf 1/1/1 2/2/1 3/3/1 4/4/1\no two\nusemtl b\nf -4 -3 -2\n")
+    sc = scenes.load_obj(str(tmp_path / "m.obj"))
+    assert sc.num_triangles == 3 and len(sc.meshes) == 2
+    assert sc.instances[0][:2] == (0, 0) and sc.instances[1][:2] == (1, 1)
+    assert sc.materials[0] == ((1.0, 2.0, 3.0), (0.2, 0.4, 0.6, 1.0))
+    v, i = sc.meshes[0]
+    assert len(v) == 4 and list(i) == [0, 1, 2, 0, 2, 3] and tuple(v["uv"][2]) == (1.0, 1.0)
+    v2, _ = sc.meshes[1]
+    np.testing.assert_allclose(v2["normal"], [[0, 0, 1]] * 3)    # no vn: face normal
+    m, nm, ins, ni, mats, nmat, keep = pack_scene(sc)
+    assert (nm, ni, nmat) == (2, 2, 2) and m[0].num_triangles == 2 and list(ins[1].myTransform)[::5] == [1.0] * 4
+
+
+def test_atrium_is_exact_and_deterministic():
+    a, b = scenes.atrium(1), scenes.atrium(1)
+    assert a.num_triangles == 262144 and len(a.materials) == 24
+    for (va, ia), (vb, ib) in zip(a.meshes, b.meshes):
+        assert np.array_equal(va, vb) and np.array_equal(ia, ib)
+    allp = np.concatenate([v["pos"] for v, _ in a.meshes])
+    assert allp.min() > -21 and allp.max() < 21 and np.isfinite(allp).all()
+    n = np.concatenate([v["normal"] for v, _ in a.meshes])
+    np.testing.assert_allclose(np.linalg.norm(n, axis=1), 1.0, rtol=1e-4)
+    for e, c in a.materials:
+        assert e == (0.0, 0.0, 0.0) and all(0.2 <= x <= 0.8 for x in c[:3])
+
+
+def test_partition_samples_covers_range_exactly():
+    for total in (0, 1, 7, 64, 4096, 4099):
+        for world in (1, 2, 3, 4, 8):
+            seen = []
+            for r in range(world):
+                f, n = partition_samples(total, world, r)
+                seen += list(range(f, f + n))
+            assert seen == list(range(total))
+    assert partition_samples(4096, 8, 3) == (1536, 512)
+
+
+def _gloo_worker(rank, world, port, tmp):
+    import torch
+    import torch.distributed as dist
+    from pathtracer_amd import distributed as ptd
+    from tests import oracle_lib
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    orc = oracle_lib.load()
+    osc = orc.scene(scenes.cornell_box())
+    W = H = 32
+    total = 10
+    c = cornell_consts(W, H)
+    first, n = ptd.partition_samples(total, world, rank)
+    acc, _, _ = osc.render(c, W, H, first, n)                  # this rank's sample block, full frame, SUM target
+    t = torch.from_numpy(acc.reshape(-1).copy())
+    t2 = t.clone()
+    red, cnt = ptd.reduce_sum_to_root(t, n)
+    ordered, cnt2 = ptd.gather_ordered_sum_to_root(t2, n)
+    if rank == 0:
+        np.save(os.path.join(tmp, "reduced.npy"), red.numpy().reshape(H, W, 4))
+        np.save(os.path.join(tmp, "ordered.npy"), ordered.numpy().reshape(H, W, 4))
+        np.save(os.path.join(tmp, "count.npy"), np.array([cnt, cnt2]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_reduce_equals_single_process(tmp_path, oracle):
+    import torch.multiprocessing as mp
+    port = 29500 + (os.getpid() % 2000)
+    mp.spawn(_gloo_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    red = np.load(tmp_path / "reduced.npy")
+    ordered = np.load(tmp_path / "ordered.npy")
+    cnt = np.load(tmp_path / "count.npy")
+    assert list(cnt) == [10, 10]
+    osc = oracle.scene(scenes.cornell_box())
+    c = cornell_consts(32, 32)
+    single, _, _ = osc.render(c, 32, 32, 0, 10)
+    # fp32 addition is not associative: (s0..s4)+(s5..s9) vs s0..s9 differ in the last bits only
+    np.testing.assert_allclose(red, single, rtol=2e-6, atol=1e-6)
+    # the ordered gather is exactly the rank-order sum of the two partial targets
+    a, _, _ = osc.render(c, 32, 32, 0, 5)
+    b, _, _ = osc.render(c, 32, 32, 5, 5)
+    assert np.array_equal(ordered, a + b)
+    assert np.array_equal(red, a + b)      # with two ranks any reduction order gives a+b
+
+
+def test_host_mirror_defaults_match_reference_header():
+    """PathTracer.h:112-131 and Sky.h:80-83 defaults, checked on the class source without creating a GPU ctx."""
+    import inspect
+    from pathtracer_amd import pathtracer
+    src = inspect.getsource(pathtracer.PathTracer.__init__)
+    for line in ("self.myAoDistance = 1.0", "self.myAccumulate = True", "self.myHalfResRender = True",
+                 "self.mySampleSky = True", "self.mySkyFallbackIntensity = 100.0", "self.myMaxRecursionDepth = 4",
+                 "self.myLightInstanceIdx = 4", "self.myLightStrength = 100.0", "self.myPhongSpecularPower = 10.0"):
+        assert line in src, line
+    a = SetupEarthAtmosphere()
+    assert a.MiePhaseG == np.float32(0.8) and a.AbsorptionDensity0LayerWidth == 25000.0
+    assert abs(a.RayleighDensityExpScale + 1 / 8000.0) < 1e-9 and abs(a.MieAbsorption[0] - 4.44e-7) < 1e-9

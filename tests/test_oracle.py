@@ -1,0 +1,210 @@
+"""CPU tests of the oracle: exact integer KATs, regression pins against tests/golden/, internal consistency
+(BVH vs brute force, sum vs running mean, Q1 jitter deviation vs literal indexing)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from pathtracer_amd import api, scenes
+from tests.common import cornell_consts, function_inputs, lookat_consts, random_rays, rel_mse
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def test_pcg4d_and_rand01_kats(oracle):
+    """Exact u32 pins derived from Random.hlsl:45-62,84-99."""
+    kat = json.load(open(os.path.join(G, "rng_kat.json")))
+    for k in kat["pcg4d"]:
+        assert list(oracle.pcg4d(k["in"])) == k["out"]
+    for k in kat["rand01_bits"]:
+        got = oracle.rand01(k["px"], k["py"], k["seed"], 5)
+        assert list(got.view(np.uint32)) == k["bits"]
+        assert ((got >= 0) & (got < 1)).all()
+
+
+def test_half_conversion_matches_ieee(oracle):
+    rng = np.random.default_rng(1)
+    vals = np.concatenate([rng.uniform(0, 1, 2000), 10.0 ** rng.uniform(-9, 5, 2000), [0.0, 1.0, 65504.0, 6e-8, 5.96e-8, 1e-10, 70000.0]]).astype(np.float32)
+    for v in vals:
+        h = oracle.lib.orc_float_to_half(float(v))
+        assert h == int(np.float32(v).astype(np.float16).view(np.uint16)), v
+        back = oracle.lib.orc_half_to_float(h)
+        assert back == float(np.uint16(h).view(np.float16)) or (np.isinf(back) and v > 65504)
+
+
+def test_encode_unorm(oracle):
+    assert oracle.encode_unorm_rgba([1, 0, 0, 1]) == 0xFF0000FF
+    assert oracle.encode_unorm_rgba([0.5, 0.5, 0.5, 1.0]) == 0xFF808080
+    assert oracle.encode_unorm_rgba([-1, 2, 0.4, 0]) == (0 | 255 << 8 | 102 << 16)
+
+
+def test_earth_atmosphere_matches_host_mirror(oracle):
+    from pathtracer_amd.pathtracer import SetupEarthAtmosphere
+    a, b = oracle.earth_atmosphere(), SetupEarthAtmosphere()
+    assert bytes(a) == bytes(b)
+    assert a.BottomRadius == 6360000.0 and a.TopRadius == 6460000.0
+
+
+def test_transmittance_lut_pins(oracle):
+    lut = oracle.transmittance_lut(oracle.earth_atmosphere())
+    g = json.load(open(os.path.join(G, "transmittance_lut_probes.json")))
+    assert int(lut.astype(np.uint64).sum()) == g["sum_u16"]
+    for p in g["probes"]:
+        assert [int(v) for v in lut[p["y"], p["x"]]] == p["rgba16f"]
+    f = lut.view(np.float16).astype(np.float32)
+    assert (f[..., 3] == 1.0).all() and (f[..., :3] >= 0).all() and (f[..., :3] <= 1).all()
+    # physically: transmittance towards the zenith from the ground is high and blue is attenuated most
+    top = f[0, 0]          # x_mu = 0: shortest path (zenith), x_r = 0: from the ground
+    assert top[0] > top[1] > top[2] > 0.5
+
+
+def test_function_tables_pinned(oracle):
+    t = np.load(os.path.join(G, "function_tables.npz"))
+    lut = oracle.transmittance_lut(oracle.earth_atmosphere())
+    c = cornell_consts(64, 64, sky=True)
+    for fn in range(1, 9):
+        x = function_inputs(fn, 256, seed=100 + fn)
+        assert np.array_equal(x, t[f"in_{fn}"]), "seeded inputs changed"
+        y = oracle.eval(fn, x, consts=c, lut=lut)
+        np.testing.assert_allclose(y, t[f"out_{fn}"], rtol=2e-6, atol=1e-30, equal_nan=True)
+
+
+def test_function_properties(oracle):
+    n = 512
+    x = function_inputs(api.PT_FN_COS_HEMISPHERE, n, 5)
+    d = oracle.eval(api.PT_FN_COS_HEMISPHERE, x)
+    np.testing.assert_allclose(np.linalg.norm(d, axis=1), 1.0, rtol=1e-5)
+    assert ((d * x[:, 2:5]).sum(1) > -1e-3).all()          # cosine lobe stays in the normal's hemisphere
+    p = oracle.eval(api.PT_FN_SPEC_PROB, function_inputs(api.PT_FN_SPEC_PROB, n, 6))
+    assert (p >= 0.1).all() and (p <= 0.9).all()
+    f = oracle.eval(api.PT_FN_FRESNEL, function_inputs(api.PT_FN_FRESNEL, n, 7))
+    assert (f >= 0.04 - 1e-6).all() and (f <= 1).all()
+    x = function_inputs(api.PT_FN_SAMPLE_PHONG, n, 8)
+    s = oracle.eval(api.PT_FN_SAMPLE_PHONG, x)
+    np.testing.assert_allclose(np.linalg.norm(s[:, :3], axis=1), 1.0, rtol=1e-4)
+    assert (s[:, 3] > 0).all()
+
+
+def test_cornell_primary_hits_pinned_and_bvh_equals_brute(oracle):
+    sc = scenes.cornell_box()
+    osc = oracle.scene(sc)
+    assert osc.num_triangles == 36
+    c = cornell_consts(64, 64)
+    g = np.load(os.path.join(G, "cornell_hits_64.npy"))
+    a = osc.primary_hits(c, 64, 64, 0)
+    b = osc.primary_hits(c, 64, 64, 0, brute=True)
+    assert np.array_equal(a["prim"], g["prim"]) and np.array_equal(a["prim"], b["prim"])
+    assert np.array_equal(a["t"].view(np.uint32), g["t"].view(np.uint32))
+    hit = a["prim"] != api.PT_MISS
+    assert 0.1 < hit.mean() < 0.3 and (a["t"][hit] > 0).all() and (a["t"][~hit] == -1).all()
+
+
+@pytest.mark.parametrize("n_tris", [1, 7, 2000])
+def test_oracle_bvh_equals_brute_on_random_soup(oracle, n_tris):
+    sc = scenes.random_triangle_soup(11, n_tris)
+    osc = oracle.scene(sc)
+    rays = random_rays(3, 4000, (0, 0, 0), (10, 10, 10))
+    a = osc.trace_rays(rays)
+    b = osc.trace_rays(rays, brute=True)
+    assert np.array_equal(a["prim"], b["prim"])
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    if n_tris == 2000:
+        assert (a["prim"] != api.PT_MISS).mean() > 0.3
+
+
+def test_tmin_tmax_are_exclusive(oracle):
+    v = np.zeros(3, dtype=api.VERTEX_DTYPE)
+    v["pos"] = [[-1, -1, 5], [1, -1, 5], [0, 1, 5]]
+    v["normal"] = [[0, 0, -1]] * 3
+    from pathtracer_amd import SceneData
+    sc = SceneData([(v, np.arange(3, dtype=np.uint32))], [(0, 0, None)], [((0, 0, 0), (1, 1, 1, 1))])
+    osc = oracle.scene(sc)
+    rays = np.zeros(1, dtype=api.RAY_DTYPE)
+    rays["dir"] = [0, 0, 1]
+    rays["tmax"] = 10.0
+    h0 = osc.trace_rays(rays, brute=True)
+    t0 = float(h0["t"][0])
+    assert h0["prim"][0] == 0 and abs(t0 - 5.0) < 1e-5
+    assert abs(h0["u"][0] - 0.25) < 1e-6 and abs(h0["v"][0] - 0.5) < 1e-6   # u: weight of v1, v: weight of v2
+    rays = np.zeros(4, dtype=api.RAY_DTYPE)
+    rays["dir"] = [0, 0, 1]
+    rays["tmin"] = [0.0, t0, 0.0, np.nextafter(np.float32(t0), np.float32(0))]
+    rays["tmax"] = [10.0, 10.0, t0, np.nextafter(np.float32(t0), np.float32(10))]
+    for brute in (True, False):
+        h = osc.trace_rays(rays, brute=brute)
+        assert list(h["prim"]) == [0, api.PT_MISS, api.PT_MISS, 0]      # tmin < t < tmax, both exclusive
+
+
+def test_cornell_image_pinned(oracle):
+    osc = oracle.scene(scenes.cornell_box())
+    c = cornell_consts(128, 128)
+    acc, st, _ = osc.render(c, 128, 128, 0, 16)
+    g = np.load(os.path.join(G, "cornell_128_16spp.npy"))
+    assert rel_mse(acc[..., :3] / 16.0, g) < 1e-9
+    gs = json.load(open(os.path.join(G, "cornell_128_16spp_stats.json")))
+    assert abs(st["rays"] - gs["rays"]) <= 4 and st["samples"] == 128 * 128 * 16
+    assert st["rays"] == st["shaded_hits"] + st["sky_misses"] or st["rays"] >= st["shaded_hits"]
+    assert (acc[..., 3] == 0).all()               # alpha stays 0 (PathTracing.hlsl:135)
+    assert np.isfinite(acc).all() and acc[..., :3].max() > 1.0   # the light is visible
+
+
+def test_running_mean_equals_sum_over_n(oracle):
+    """The reference's running mean (PathTracing.hlsl:134-137) vs the product's sum target: same image."""
+    osc = oracle.scene(scenes.cornell_box())
+    c = cornell_consts(48, 48)
+    s, _, _ = osc.render(c, 48, 48, 0, 12, accum_mode=0)
+    m, _, _ = osc.render(c, 48, 48, 0, 12, accum_mode=1)
+    np.testing.assert_allclose(m[..., :3], s[..., :3] / 12.0, rtol=2e-6, atol=1e-7)
+    # accumulation continues across calls: 8 then 4 more samples == 12 at once (sum mode is exactly additive)
+    a, _, _ = osc.render(c, 48, 48, 0, 8)
+    a, _, _ = osc.render(c, 48, 48, 8, 4, accum=a)
+    assert np.array_equal(a, s)
+
+
+def test_q1_jitter_deviation_has_the_same_expected_image(oracle):
+    """Q1: uPixel+jitter written to uPixel (ours) vs uPixel+jitter-0.5 written to trunc() (literal reference)."""
+    osc = oracle.scene(scenes.cornell_box())
+    w = h = 24
+    c = cornell_consts(w, h, depth=1)
+    n = 192
+    a, _, _ = osc.render(c, w, h, 0, n, jitter_mode=0)
+    b, _, _ = osc.render(c, w, h, 0, n, jitter_mode=1, accum_mode=0)
+    a, b = a[1:-1, 1:-1, :3] / n, b[1:-1, 1:-1, :3] / n   # literal mode starves/doubles border texels
+    # the literal mode delivers a varying number of samples per texel, so compare block means within noise
+    assert abs(a.mean() - b.mean()) / a.mean() < 0.08
+
+
+def test_sky_render_is_finite_and_blue(oracle):
+    sc = scenes.cornell_box()
+    osc = oracle.scene(sc)
+    lut = oracle.transmittance_lut(oracle.earth_atmosphere())
+    c = cornell_consts(32, 32, sky=True)
+    acc, st, _ = osc.render(c, 32, 32, 0, 2, lut=lut)
+    assert np.isfinite(acc).all() and st["sky_misses"] > 0
+    sky_px = acc[0, 0, :3]      # top-left corner looks past the box into the sky
+    assert sky_px[2] > sky_px[0] > 0
+
+
+def test_scene_flatten_applies_transform_to_positions_only(oracle):
+    from pathtracer_amd import SceneData
+    v = np.zeros(3, dtype=api.VERTEX_DTYPE)
+    v["pos"] = [[0, 0, 0], [1, 0, 0], [0, 1, 0]]
+    v["normal"] = [[0, 0, 1]] * 3
+    T = np.eye(4, dtype=np.float32)
+    T[:3, 3] = [10, 20, 30]                        # translation in the last column
+    sc = SceneData([(v, np.arange(3, dtype=np.uint32))], [(0, 0, None), (0, 0, T.T.reshape(16))], [((0, 0, 0), (1, 1, 1, 1))])
+    osc = oracle.scene(sc)
+    assert osc.num_triangles == 2
+    t0, i0 = osc.triangle(0)
+    t1, i1 = osc.triangle(1)
+    assert (i0, i1) == (0, 1)
+    np.testing.assert_array_equal(t1, t0 + np.array([10, 20, 30], dtype=np.float32))
+
+
+def test_oracle_rejects_bad_indices(oracle):
+    from pathtracer_amd import SceneData
+    v = np.zeros(3, dtype=api.VERTEX_DTYPE)
+    sc = SceneData([(v, np.arange(3, dtype=np.uint32))], [(0, 3, None)], [((0, 0, 0), (1, 1, 1, 1))])
+    with pytest.raises(ValueError):
+        oracle.scene(sc)
