@@ -1,0 +1,374 @@
+"""GPU parity tests: the HIP path (through the C-ABI) against the CPU oracle and the committed fixtures.
+Bars: bit-exact for integer / index work (RNG, triangle ids, t/u/v of the shared watertight test, LUT halfs);
+rtol for fp32 shading functions that call transcendentals (libm vs ocml); image relMSE < 1e-4 (north_star)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from pathtracer_amd import api, scenes
+from pathtracer_amd.context import SceneData
+from tests.common import cornell_consts, function_inputs, lookat_consts, random_rays, rel_mse
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module")
+def cornell(ctx, oracle):
+    sc = scenes.cornell_box()
+    ctx.scene_create(sc)
+    return sc, oracle.scene(sc)
+
+
+def _bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+# ---------------------------------------------------------------------------------------------- integer / exact
+def test_rand01_kats_on_device(ctx):
+    kat = json.load(open(os.path.join(G, "rng_kat.json")))
+    rows = [[k["px"], k["py"], k["seed"], 5] for k in kat["rand01_bits"]]
+    out = ctx.debug_eval(api.PT_FN_RAND01, np.array(rows, dtype=np.float32))
+    for k, o in zip(kat["rand01_bits"], out):
+        assert list(_bits(o[:5])) == k["bits"]
+
+
+def test_rand01_matches_oracle_bitwise(ctx, oracle):
+    x = function_inputs(api.PT_FN_RAND01, 2048, 9)
+    assert np.array_equal(_bits(ctx.debug_eval(api.PT_FN_RAND01, x)), _bits(oracle.eval(api.PT_FN_RAND01, x)))
+
+
+def test_transmittance_lut_matches_oracle(ctx, oracle):
+    atm = oracle.earth_atmosphere()
+    ctx.sky_set(atm)
+    lut, olut = ctx.sky_lut_read(), oracle.transmittance_lut(atm)
+    diff = lut.astype(np.int32) - olut.astype(np.int32)
+    # expf differs by <= 1 ulp between ocml and libm: allow a handful of halfs to round the other way by one step
+    assert (np.abs(diff) <= 1).all() and (diff != 0).mean() < 1e-3
+    g = json.load(open(os.path.join(G, "transmittance_lut_probes.json")))
+    for p in g["probes"]:
+        assert np.abs(lut[p["y"], p["x"]].astype(np.int32) - np.array(p["rgba16f"])).max() <= 1
+
+
+# ---------------------------------------------------------------------------------------------- shading functions
+@pytest.mark.parametrize("fn,rtol,exact", [
+    (api.PT_FN_FRESNEL, 2e-6, False), (api.PT_FN_SPEC_PROB, 0, True), (api.PT_FN_SAMPLE_PHONG, 2e-5, False),
+    (api.PT_FN_EVAL_PHONG, 5e-5, False), (api.PT_FN_COS_HEMISPHERE, 2e-5, False), (api.PT_FN_LAMBERT, 0, True),
+    (api.PT_FN_PRIMARY_RAY, 0, True)])
+def test_shading_functions_match_oracle_and_fixture(ctx, oracle, fn, rtol, exact):
+    c = cornell_consts(64, 64, sky=True)
+    x = function_inputs(fn, 4096, seed=100 + fn)
+    got, want = ctx.debug_eval(fn, x, consts=c), oracle.eval(fn, x, consts=c)
+    if exact:      # no transcendental on the path: +,-,*,/,sqrt are IEEE on both sides
+        assert np.array_equal(_bits(got), _bits(want))
+    else:
+        np.testing.assert_allclose(got, want, rtol=rtol, atol=1e-5, equal_nan=True)   # atol: components of unit vectors near 0
+    t = np.load(os.path.join(G, "function_tables.npz"))
+    x256 = function_inputs(fn, 256, seed=100 + fn)
+    assert np.array_equal(x256, t[f"in_{fn}"])
+    np.testing.assert_allclose(ctx.debug_eval(fn, x256, consts=c), t[f"out_{fn}"], rtol=max(rtol, 2e-6), atol=1e-5, equal_nan=True)
+
+
+def test_sky_function_matches_oracle(ctx, oracle):
+    atm = oracle.earth_atmosphere()
+    ctx.sky_set(atm)
+    olut = oracle.transmittance_lut(atm)
+    c = cornell_consts(64, 64, sky=True)
+    x = function_inputs(api.PT_FN_SKY, 4096, seed=107)
+    got, want = ctx.debug_eval(api.PT_FN_SKY, x, consts=c), oracle.eval(api.PT_FN_SKY, x, consts=c, lut=olut)
+    assert np.isfinite(got).all()
+    # positions ~6.36e6 m in fp32 amplify 1-ulp expf differences: relative to the brightest channel of each row
+    scale = np.maximum(np.abs(want).max(axis=1, keepdims=True), 1e-3)
+    assert (np.abs(got - want) / scale).max() < 2e-3
+    assert np.median(np.abs(got - want) / scale) < 1e-5
+    c.mySampleSky = 0
+    api.fill3(c.mySkyFallbackEmission, (3.0, 2.0, 1.0))
+    assert np.array_equal(ctx.debug_eval(api.PT_FN_SKY, x[:4], consts=c), np.tile([3.0, 2.0, 1.0], (4, 1)).astype(np.float32))
+
+
+# ---------------------------------------------------------------------------------------------- intersection
+def test_cornell_primary_hits_bit_identical(ctx, cornell):
+    sc, osc = cornell
+    for (w, h, sample) in ((64, 64, 0), (512, 512, 0), (512, 512, 63), (33, 17, 5), (1, 1, 0)):
+        c = cornell_consts(w, h)
+        got, want = ctx.primary_hits(c, w, h, sample), osc.primary_hits(c, w, h, sample)
+        assert np.array_equal(got["prim"], want["prim"]), (w, h, sample)
+        assert np.array_equal(_bits(got["t"]), _bits(want["t"]))
+        assert np.array_equal(_bits(got["u"]), _bits(want["u"])) and np.array_equal(_bits(got["v"]), _bits(want["v"]))
+    g = np.load(os.path.join(G, "cornell_hits_64.npy"))
+    got = ctx.primary_hits(cornell_consts(64, 64), 64, 64, 0)
+    assert np.array_equal(got["prim"], g["prim"]) and np.array_equal(_bits(got["t"]), _bits(g["t"]))
+
+
+@pytest.mark.parametrize("n_tris,n_rays", [(1, 2000), (3, 2000), (4, 2000), (500, 20000), (20000, 200000)])
+def test_random_soup_incoherent_rays_match_oracle(ctx, oracle, n_tris, n_rays):
+    sc = scenes.random_triangle_soup(21 + n_tris, n_tris)
+    ctx.scene_create(sc)
+    osc = oracle.scene(sc)
+    rays = random_rays(n_tris, n_rays, (0, 0, 0), (10, 10, 10))
+    got = ctx.trace_rays(rays)
+    want = osc.trace_rays(rays, brute=(n_tris <= 500))
+    assert np.array_equal(got["prim"], want["prim"])
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    if n_tris >= 500:
+        assert (got["prim"] != api.PT_MISS).mean() > 0.05
+
+
+def test_atrium_primary_and_secondary_rays_bit_identical(ctx, oracle):
+    sc = scenes.atrium(1)
+    ctx.scene_create(sc)
+    info = ctx.scene_info()
+    assert info.num_triangles == 262144 and info.num_bvh_nodes > 1000 and info.bvh_max_depth >= 4
+    osc = oracle.scene(sc)
+    w, h = 320, 180
+    c = lookat_consts(w, h, scenes.ATRIUM_CAM)
+    got, (want, rays) = ctx.primary_hits(c, w, h, 3), osc.primary_hits(c, w, h, 3, want_rays=True)
+    assert np.array_equal(got["prim"], want["prim"])
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    assert (got["prim"] != api.PT_MISS).mean() > 0.5
+    # incoherent secondary rays: from the primary hit points into random directions, tmin 0.001 (PathTracing.hlsl:127)
+    hit = (want["prim"] != api.PT_MISS).reshape(-1)
+    o = (rays["origin"] + rays["dir"] * want["t"][..., None]).reshape(-1, 3)[hit]
+    sec = random_rays(5, len(o), (0, 0, 0), (1, 1, 1), tmin=0.001)
+    sec["origin"] = o
+    g2, w2 = ctx.trace_rays(sec), osc.trace_rays(sec)
+    assert np.array_equal(g2["prim"], w2["prim"]) and np.array_equal(g2.view(np.uint32), w2.view(np.uint32))
+
+
+def test_edge_cases_empty_scene_axis_rays_degenerate_triangles(ctx, oracle):
+    v = np.zeros(0, dtype=api.VERTEX_DTYPE)
+    empty = SceneData([(v, np.zeros(0, dtype=np.uint32))], [(0, 0, None)], [((0, 0, 0), (1, 1, 1, 1))])
+    ctx.scene_create(empty)
+    assert ctx.scene_info().num_triangles == 0
+    rays = random_rays(1, 1000, (0, 0, 0), (1, 1, 1))
+    h = ctx.trace_rays(rays)
+    assert (h["prim"] == api.PT_MISS).all() and (h["t"] == -1).all()
+    assert len(ctx.trace_rays(rays[:0])) == 0
+    # axis-aligned rays (zero direction components), rays inside flat boxes, zero-area triangles
+    v = np.zeros(9, dtype=api.VERTEX_DTYPE)
+    v["pos"] = [[0, 0, 0], [4, 0, 0], [0, 4, 0], [0, 0, 2], [4, 0, 2], [0, 4, 2], [1, 1, 1], [1, 1, 1], [1, 1, 1]]
+    sc = SceneData([(v, np.arange(9, dtype=np.uint32))], [(0, 0, None)], [((0, 0, 0), (1, 1, 1, 1))])
+    ctx.scene_create(sc)
+    osc = oracle.scene(sc)
+    r = np.zeros(8, dtype=api.RAY_DTYPE)
+    r["origin"] = [[1, 1, -1], [1, 1, 5], [1, 1, 1], [-1, 1, 0], [1, 1, -1], [0, 0, -1], [2, 2, -1], [1, 1, 0]]
+    r["dir"] = [[0, 0, 1], [0, 0, -1], [0, 0, 1], [1, 0, 0], [0, 0, -1], [0, 0, 1], [0, 0, 1], [0, 0, 1]]
+    r["tmax"] = 10000.0
+    got, want = ctx.trace_rays(r), osc.trace_rays(r, brute=True)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    assert list(got["prim"][:3]) == [0, 1, 1]
+
+
+def test_tmin_tmax_exclusive_on_device(ctx, oracle):
+    v = np.zeros(3, dtype=api.VERTEX_DTYPE)
+    v["pos"] = [[-1, -1, 5], [1, -1, 5], [0, 1, 5]]
+    sc = SceneData([(v, np.arange(3, dtype=np.uint32))], [(0, 0, None)], [((0, 0, 0), (1, 1, 1, 1))])
+    ctx.scene_create(sc)
+    r = np.zeros(1, dtype=api.RAY_DTYPE)
+    r["dir"] = [0, 0, 1]
+    r["tmax"] = 10.0
+    t0 = np.float32(ctx.trace_rays(r)["t"][0])
+    r = np.zeros(4, dtype=api.RAY_DTYPE)
+    r["dir"] = [0, 0, 1]
+    r["tmin"] = [0.0, t0, 0.0, np.nextafter(t0, np.float32(0))]
+    r["tmax"] = [10.0, 10.0, t0, np.nextafter(t0, np.float32(10))]
+    assert list(ctx.trace_rays(r)["prim"]) == [0, api.PT_MISS, api.PT_MISS, 0]
+
+
+def test_instance_transform_and_flatten_order(ctx, oracle):
+    v = np.zeros(3, dtype=api.VERTEX_DTYPE)
+    v["pos"] = [[-1, -1, 0], [1, -1, 0], [0, 1, 0]]
+    v["normal"] = [[0, 0, -1]] * 3
+    T = np.eye(4, dtype=np.float32)
+    T[:3, :3] = [[0.5, 0, 0], [0, 2.0, 0], [0, 0, 1]]
+    T[:3, 3] = [3, 0, 7]
+    sc = SceneData([(v, np.arange(3, dtype=np.uint32))], [(0, 0, None), (0, 0, T.T.reshape(16))], [((0, 0, 0), (1, 1, 1, 1))])
+    ctx.scene_create(sc)
+    osc = oracle.scene(sc)
+    rays = random_rays(2, 5000, (-1, -2, 0), (4, 2, 7))
+    got, want = ctx.trace_rays(rays), osc.trace_rays(rays, brute=True)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    assert set(np.unique(got["prim"])) >= {0, 1}
+
+
+# ---------------------------------------------------------------------------------------------- images
+def test_cornell_image_vs_oracle_and_fixture(ctx, cornell):
+    sc, osc = cornell
+    ctx.scene_create(sc)
+    w = h = 128
+    c = cornell_consts(w, h)
+    ctx.accum_reset(w, h)
+    ctx.stats_reset()
+    ctx.render(c, w, h, 0, 16)
+    img = ctx.accum_read()
+    acc, ost, ps = osc.render(c, w, h, 0, 16, per_sample=True)
+    assert rel_mse(img, acc / 16.0) < 1e-8          # same RNG streams: far below the 1e-4 bar
+    assert rel_mse(img, np.load(os.path.join(G, "cornell_128_16spp.npy"))) < 1e-8
+    assert (img[..., 3] == 0).all() and np.isfinite(img).all()
+    st = ctx.stats()
+    assert st.samples == w * h * 16 and abs(int(st.rays) - ost["rays"]) <= 8 and abs(int(st.shaded_hits) - ost["shaded_hits"]) <= 8
+    # per-sample agreement: render sample 5 alone and compare with the oracle's per-sample radiance
+    ctx.accum_reset(w, h)
+    ctx.render(c, w, h, 5, 1)
+    one, _ = ctx.accum_read_sum()
+    d = np.abs(one[..., :3] - ps[5]) / np.maximum(np.abs(ps[5]), 1e-3)
+    assert (d > 1e-3).mean() < 1e-3                  # a few samples may branch differently on a 1-ulp pow/sin difference
+
+
+def test_cornell_c1_full_config(ctx, cornell):
+    """BASELINE config C1: Cornell 512x512, 64 spp, depth 4, sky off."""
+    sc, osc = cornell
+    ctx.scene_create(sc)
+    w = h = 512
+    c = cornell_consts(w, h)
+    ctx.accum_reset(w, h)
+    ctx.render(c, w, h, 0, 64)
+    img = ctx.accum_read()
+    acc, _, _ = osc.render(c, w, h, 0, 64)
+    r = rel_mse(img, acc / 64.0)
+    assert r < 1e-4, r
+    assert r < 1e-7
+
+
+def test_sky_image_and_fallback_vs_oracle(ctx, cornell, oracle):
+    sc, osc = cornell
+    ctx.scene_create(sc)
+    atm = oracle.earth_atmosphere()
+    ctx.sky_set(atm)
+    olut = oracle.transmittance_lut(atm)
+    w, h = 96, 64
+    for sky, fb in ((True, 0.0), (False, 100.0)):     # Sky.cpp sky, and the reference default fallback 100
+        c = cornell_consts(w, h, sky=sky, fallback=fb)
+        ctx.accum_reset(w, h)
+        ctx.render(c, w, h, 0, 8)
+        img = ctx.accum_read()
+        acc, _, _ = osc.render(c, w, h, 0, 8, lut=olut)
+        assert rel_mse(img, acc / 8.0) < 1e-6, (sky, rel_mse(img, acc / 8.0))
+
+
+def test_atrium_image_vs_oracle(ctx, oracle):
+    sc = scenes.atrium(1)
+    ctx.scene_create(sc)
+    osc = oracle.scene(sc)
+    atm = oracle.earth_atmosphere()
+    ctx.sky_set(atm)
+    olut = oracle.transmittance_lut(atm)
+    w, h = 240, 135
+    c = lookat_consts(w, h, scenes.ATRIUM_CAM)
+    ctx.accum_reset(w, h)
+    ctx.render(c, w, h, 0, 4)
+    img = ctx.accum_read()
+    acc, _, _ = osc.render(c, w, h, 0, 4, lut=olut)
+    assert rel_mse(img, acc / 4.0) < 1e-4
+    assert img[..., :3].mean() > 0
+
+
+# ---------------------------------------------------------------------------------------------- full-size properties
+def test_full_size_properties_1080p(ctx, oracle):
+    """At BASELINE's full size (1920x1080 atrium) the oracle is too slow: check size-independent properties."""
+    sc = scenes.atrium(1)
+    ctx.scene_create(sc)
+    ctx.sky_set(oracle.earth_atmosphere())
+    w, h = 1920, 1080
+    c = lookat_consts(w, h, scenes.ATRIUM_CAM)
+    ctx.set_option(api.PT_OPT_SAMPLES_PER_BATCH, 4)
+    ctx.accum_reset(w, h)
+    ctx.stats_reset()
+    ctx.render(c, w, h, 0, 8)
+    a, n = ctx.accum_read_sum()
+    st = ctx.stats()
+    assert n == 8 and st.samples == w * h * 8
+    assert st.rays == st.shaded_hits + st.sky_misses                 # every ray either shades a hit or samples the sky
+    assert w * h * 8 <= st.rays <= w * h * 8 * 5                     # depth 4 => at most 5 rays per sample
+    assert np.isfinite(a).all() and (a[..., :3] >= 0).all() and (a[..., 3] == 0).all()
+    # determinism + independence from the batch split: 8 at once == 3 + 5, bit for bit (resolve adds in sample order)
+    ctx.set_option(api.PT_OPT_SAMPLES_PER_BATCH, 3)
+    ctx.accum_reset(w, h)
+    ctx.render(c, w, h, 0, 3)
+    ctx.render(c, w, h, 3, 5)
+    b, _ = ctx.accum_read_sum()
+    assert np.array_equal(a, b)
+    # virtual 2-GPU partition on one device: sum of the two per-"rank" targets == single target up to fp32 reassociation
+    ctx.accum_reset(w, h)
+    ctx.render(c, w, h, 0, 4)
+    p0, _ = ctx.accum_read_sum()
+    ctx.accum_reset(w, h)
+    ctx.render(c, w, h, 4, 4)
+    p1, _ = ctx.accum_read_sum()
+    assert rel_mse(p0 + p1, a) < 1e-12
+    # counting traversal returns the same image and sane per-ray figures
+    ctx.set_option(api.PT_OPT_COUNT_TRAVERSAL, 1)
+    ctx.stats_reset()
+    ctx.accum_reset(w, h)
+    ctx.render(c, w, h, 0, 3)
+    ctx.render(c, w, h, 3, 5)
+    cimg, _ = ctx.accum_read_sum()
+    st = ctx.stats()
+    ctx.set_option(api.PT_OPT_COUNT_TRAVERSAL, 0)
+    ctx.set_option(api.PT_OPT_SAMPLES_PER_BATCH, 0)
+    assert np.array_equal(cimg, a)
+    assert 2 < st.nodes_visited / st.rays < 200 and 0.5 < st.tris_tested / st.rays < 100
+
+
+# ---------------------------------------------------------------------------------------------- API behaviour
+def test_error_codes(oracle):
+    from pathtracer_amd import Context
+    c2 = Context(0)
+    consts = cornell_consts(8, 8)
+    with pytest.raises(api.PtError) as e:
+        c2.render(consts, 8, 8, 0, 1)
+    assert e.value.code == api.PT_ERR_NO_SCENE
+    c2.scene_create(scenes.cornell_box())
+    with pytest.raises(api.PtError) as e:
+        c2.render(consts, 8, 8, 0, 1)
+    assert e.value.code == api.PT_ERR_NO_TARGET
+    c2.accum_reset(8, 8)
+    with pytest.raises(api.PtError) as e:
+        c2.render(consts, 16, 8, 0, 1)
+    assert e.value.code == api.PT_ERR_SIZE_MISMATCH
+    sky = cornell_consts(8, 8, sky=True)
+    with pytest.raises(api.PtError) as e:
+        c2.render(sky, 8, 8, 0, 1)
+    assert e.value.code == api.PT_ERR_NO_SKY
+    consts.myMaxRecursionDepth = 1000
+    with pytest.raises(api.PtError) as e:
+        c2.render(consts, 8, 8, 0, 1)
+    assert e.value.code == api.PT_ERR_INVALID_ARG
+    consts.myMaxRecursionDepth = 0                   # depth 0: exactly one ray per sample (inclusive loop bound, Q2)
+    c2.stats_reset()
+    c2.render(consts, 8, 8, 0, 2)
+    c2.render(consts, 8, 8, 2, 0)                    # zero samples is a no-op
+    assert c2.stats().rays == 8 * 8 * 2
+    bad = SceneData([(np.zeros(3, dtype=api.VERTEX_DTYPE), np.array([0, 1, 7], dtype=np.uint32))], [(0, 0, None)], [((0, 0, 0), (1, 1, 1, 1))])
+    with pytest.raises(api.PtError) as e:
+        c2.scene_create(bad)
+    assert e.value.code == api.PT_ERR_INVALID_ARG
+    c2.close()
+
+
+def test_external_target_via_torch_and_host_mirror(ctx, oracle):
+    import torch
+    from pathtracer_amd import PathTracer
+    from pathtracer_amd import distributed as ptd
+    pt = PathTracer(0, 128, 96)
+    assert (pt.myOutputWidth, pt.myOutputHeight) == (64, 48)          # myHalfResRender default (PathTracer.cpp:849-852)
+    sc = scenes.cornell_box()
+    pt.LoadScene(sc, scenes.CORNELL_CAM_POS)
+    pt.mySampleSky = False
+    pt.mySkyFallbackIntensity = 0.0
+    t = ptd.bind_torch_target(pt.ctx, 64, 48, torch.device("cuda", 0))
+    pt.myAccumulationNeedsClear = False
+    pt.RenderRT(4)
+    pt.RenderRT(4)
+    assert pt.myNumAccumulationFrames == 8
+    pt.ctx.synchronize()
+    total = t.reshape(48, 64, 4).cpu().numpy()
+    osc = oracle.scene(sc)
+    acc, _, _ = osc.render(pt.BuildRtConsts(), 64, 48, 0, 8)
+    assert rel_mse(total, acc) < 1e-8
+    red, cnt = ptd.reduce_sum_to_root(t, 8)                            # world size 1: identity
+    assert cnt == 8 and red.data_ptr() == t.data_ptr()
+    pt.ctx.accum_bind(0, 0, 0)
+    pt.ctx.close()
