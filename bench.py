@@ -162,6 +162,9 @@ def main():
             "bytes_per_launch": round(bytes_per_ray * se.rays / max(1, se.extend_launches), 1),
             "extend_share_of_render": round(se.extend_ms / max(se.render_ms, 1e-9), 4),
             "extend_mrays_per_s": round(se.rays / max(ext_s, 1e-12) / 1e6, 2),
+            "extend_mrays_per_s_by_bounce": [round(se.rays_bounce[b] / max(se.extend_ms_bounce[b], 1e-9) / 1e3, 1)
+                                             for b in range(16) if se.rays_bounce[b] > 0],
+            "secondary_mrays_per_s": round(sum(se.rays_bounce[1:]) / max(sum(se.extend_ms_bounce[1:]), 1e-9) / 1e3, 1),
         }
 
     cpu_baseline = None

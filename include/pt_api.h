@@ -163,6 +163,8 @@ typedef struct PtStats {
   uint64_t extend_launches;/* launches of the traversal (extend) kernel */
   double extend_ms;        /* sum of their durations, HIP events on the ctx stream (only when timing is on) */
   double render_ms;        /* sum of whole pt_render durations, HIP events (only when timing is on) */
+  uint64_t rays_bounce[16];      /* rays traced at bounce b (b >= 15 folded into [15]) */
+  double extend_ms_bounce[16];   /* extend-kernel time at bounce b (only when timing is on) */
 } PtStats;
 
 typedef struct PtSceneInfo {

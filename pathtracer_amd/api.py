@@ -99,7 +99,8 @@ class PtMaterial(C.Structure):
 class PtStats(C.Structure):
     _fields_ = [("samples", C.c_uint64), ("rays", C.c_uint64), ("shaded_hits", C.c_uint64), ("sky_misses", C.c_uint64),
                 ("nodes_visited", C.c_uint64), ("tris_tested", C.c_uint64), ("extend_launches", C.c_uint64),
-                ("extend_ms", C.c_double), ("render_ms", C.c_double)]
+                ("extend_ms", C.c_double), ("render_ms", C.c_double),
+                ("rays_bounce", C.c_uint64 * 16), ("extend_ms_bounce", C.c_double * 16)]
 
 
 class PtSceneInfo(C.Structure):

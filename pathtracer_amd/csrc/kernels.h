@@ -18,16 +18,20 @@ struct DeviceScene {
   uint32_t stack_entries = 0;          // LDS stack entries per lane needed by trace_closest
 };
 
-// device counter block (u32), zeroed at the start of every wavefront batch
+// device counter block (u32), zeroed at the start of every wavefront batch. Every counter sits on its own
+// 256-byte line (CTR_AT): returning atomics on one line serialise, so hot counters must not share one.
+#define CTR_AT(i) ((i) * 64)
 enum {
   CTR_QCOUNT0 = 0,      // [0..63]   rays queued for bounce b
   CTR_WORK0 = 64,       // [64..127] work-distribution cursor of the extend kernel for bounce b
   CTR_SKY = 128,        // sky-queue length
   CTR_SHADED = 129,     // ClosestHit-equivalents this batch
-  CTR_WORDS = 160
+  CTR_MISS = 130,       // rays that hit nothing (SampleSkyLuminance calls, sky on or off)
+  CTR_SLOTS = 132,
+  CTR_WORDS = 132 * 64
 };
 // persistent device statistics (u64)
-enum { ST_SAMPLES = 0, ST_RAYS, ST_SHADED, ST_SKY, ST_NODES, ST_TRIS, ST_WORDS = 8 };
+enum { ST_SAMPLES = 0, ST_RAYS, ST_SHADED, ST_SKY, ST_NODES, ST_TRIS, ST_RAYS_BOUNCE0 = 8, ST_WORDS = 8 + 64 };
 
 struct WavefrontBuffers {
   float4* ray_o[2] = {nullptr, nullptr};  // origin.xyz, tmin

@@ -38,6 +38,40 @@ __device__ __forceinline__ uint32_t wave_append(uint32_t* counter, bool pred) {
   return base + prefix;
 }
 
+
+// Block-aggregated append into two queues at once: one returning atomic per queue per BLOCK iteration (a single
+// counter word sustains only ~90 returning atomics/us chip-wide, so per-wave appends would bound the kernel).
+// Must be reached by every thread of the block; `parity` alternates per call so one barrier pair suffices.
+#define PT_SHADE_THREADS 1024
+struct BlockAppendLds {
+  uint32_t cnt[2][2][PT_SHADE_THREADS / 64];   // [parity][queue][wave] -> count, then exclusive prefix
+  uint32_t base[2][2];                          // [parity][queue]
+};
+__device__ __forceinline__ void block_append2(BlockAppendLds& L, int parity, uint32_t* counter0, bool pred0,
+                                              uint32_t* counter1, bool pred1, uint32_t& slot0, uint32_t& slot1) {
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+  const unsigned long long m0 = __ballot(pred0), m1 = __ballot(pred1);
+  if (lane == 0u) {
+    L.cnt[parity][0][wave] = (uint32_t)__popcll(m0);
+    L.cnt[parity][1][wave] = (uint32_t)__popcll(m1);
+  }
+  __syncthreads();
+  if (threadIdx.x < 2u) {
+    const uint32_t q = threadIdx.x;
+    uint32_t run = 0u;
+    for (uint32_t w = 0; w < nwaves; ++w) {
+      const uint32_t c = L.cnt[parity][q][w];
+      L.cnt[parity][q][w] = run;
+      run += c;
+    }
+    L.base[parity][q] = run ? atomicAdd(q == 0u ? counter0 : counter1, run) : 0u;
+  }
+  __syncthreads();
+  const unsigned long long below = (1ull << lane) - 1ull;
+  slot0 = L.base[parity][0] + L.cnt[parity][0][wave] + (uint32_t)__popcll(m0 & below);
+  slot1 = L.base[parity][1] + L.cnt[parity][1][wave] + (uint32_t)__popcll(m1 & below);
+}
+
 // ------------------------------------------------------------------------------------------------ transmittance LUT
 // compute_transmittance_lut.hlsl main, [numthreads(8,8,1)] over 256x64 (Sky.cpp:145)
 __global__ void __launch_bounds__(256) k_transmittance_lut(PtAtmosphere atm, uint2* __restrict__ lut) {
@@ -54,7 +88,7 @@ __global__ void __launch_bounds__(256) k_generate(PtRtConsts c, float4* __restri
                                                   uint32_t* __restrict__ counters, uint32_t w, uint32_t h,
                                                   uint32_t first_sample, uint32_t n_paths) {
   const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p == 0) counters[CTR_QCOUNT0] = n_paths;
+  if (p == 0) counters[CTR_AT(CTR_QCOUNT0)] = n_paths;
   if (p >= n_paths) return;
   const uint32_t wh = w * h;
   const uint32_t pix = p % wh, si = p / wh;
@@ -79,7 +113,21 @@ __global__ void __launch_bounds__(256) k_generate(PtRtConsts c, float4* __restri
 }
 
 // ------------------------------------------------------------------------------------------------ extend
-// Persistent waves: each wave claims 64 consecutive queue slots with one atomic, traces them, repeats.
+// Persistent waves. Each wave owns a local pool of queue slots (claimed from the global cursor in chunks, one atomic
+// per chunk: a single word sustains only ~90 returning atomics/us chip-wide, so per-64-ray claims would bound the
+// kernel) and keeps its 64 lanes busy: lanes whose ray has finished are refilled from the pool once enough of them are
+// idle (FETCH_MIN), and triangle tests are postponed to the LDS stack while too few lanes have any (POSTPONE_*), so
+// that the wave spends its instructions on box tests or on triangle tests with most lanes active.
+#ifndef PT_FETCH_MIN
+#define PT_FETCH_MIN 16
+#endif
+#ifndef PT_POSTPONE_NUM
+#define PT_POSTPONE_NUM 1   // postpone while (lanes with triangles) * DEN < (busy lanes) * NUM
+#endif
+#ifndef PT_POSTPONE_DEN
+#define PT_POSTPONE_DEN 4
+#endif
+
 template <bool COUNT>
 __global__ void __launch_bounds__(256) k_extend(const uint4* __restrict__ nodes, const uint4* __restrict__ tris,
                                                 const float4* __restrict__ ray_o, const float4* __restrict__ ray_d,
@@ -90,20 +138,87 @@ __global__ void __launch_bounds__(256) k_extend(const uint4* __restrict__ nodes,
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   uint2* stk = s_stack + (size_t)wave * stack_entries * 64u + lane;
   const uint32_t n = *count_ptr;
+  // chunk: large enough to amortise the atomic, small enough to balance the tail (~8 chunks per wave)
+  const uint32_t total_waves = gridDim.x * (blockDim.x >> 6);
+  uint32_t chunk = (n / (total_waves * 8u) + 63u) & ~63u;
+  chunk = chunk < 64u ? 64u : (chunk > 2048u ? 2048u : chunk);
+
+  uint32_t pool_next = 0u, pool_end = 0u;   // wave-uniform
+  bool exhausted = false;                   // wave-uniform
+  bool busy = false;
+  uint32_t ray_i = 0u;
+  Traverser tr;
   uint32_t n_nodes = 0u, n_tris = 0u;
+
   for (;;) {
-    uint32_t base = 0u;
-    if (lane == 0u) base = atomicAdd(work_cursor, 64u);
-    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-    if (base >= n) break;
-    const uint32_t i = base + lane;
-    if (i < n) {
-      const float4 ro = ray_o[(size_t)i * stride], rd = ray_d[(size_t)i * stride];
-      TraceRay r;
-      r.ox = ro.x; r.oy = ro.y; r.oz = ro.z; r.tmin = ro.w;
-      r.dx = rd.x; r.dy = rd.y; r.dz = rd.z; r.tmax = rd.w;
-      const HitRec hr = trace_closest<COUNT>(nodes, tris, r, stk, n_nodes, n_tris);
-      hits[i] = make_float4(hr.t, hr.u, hr.v, __uint_as_float(hr.prim));
+    // ---- refill idle lanes from the wave's pool ----
+    const unsigned long long idle_mask = __ballot(!busy);
+    const uint32_t n_idle = (uint32_t)__popcll(idle_mask);
+    if (n_idle == 64u && exhausted) break;
+    if (!exhausted && (n_idle >= PT_FETCH_MIN)) {
+      if (pool_next >= pool_end) {
+        uint32_t base = 0u;
+        if (lane == 0u) base = atomicAdd(work_cursor, chunk);
+        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+        if (base >= n) {
+          exhausted = true;
+        } else {
+          pool_next = base;
+          pool_end = base + chunk < n ? base + chunk : n;
+        }
+      }
+      if (!exhausted) {
+        const uint32_t avail = pool_end - pool_next;
+        const uint32_t take = n_idle < avail ? n_idle : avail;
+        const uint32_t rank = (uint32_t)__popcll(idle_mask & ((1ull << lane) - 1ull));
+        if (!busy && rank < take) {
+          ray_i = pool_next + rank;
+          const float4 ro = ray_o[(size_t)ray_i * stride], rd = ray_d[(size_t)ray_i * stride];
+          TraceRay r;
+          r.ox = ro.x; r.oy = ro.y; r.oz = ro.z; r.tmin = ro.w;
+          r.dx = rd.x; r.dy = rd.y; r.dz = rd.z; r.tmax = rd.w;
+          tr.init(r);
+          busy = true;
+        }
+        pool_next += take;
+      }
+      if (__ballot(busy) == 0ull) continue;   // nothing to do yet (pool was empty): claim again or finish
+    }
+
+    // ---- one traversal iteration for the busy lanes ----
+    const uint32_t n_busy = (uint32_t)__popcll(__ballot(busy));
+    if (busy) {
+      if (tr.has_node_work()) {
+        tr.node_step(nodes, stk);
+        if (COUNT) ++n_nodes;
+      } else {
+        tr.tg = tr.ng;
+        tr.ng = make_uint2(0u, 0u);
+      }
+    }
+    for (;;) {
+      const bool has = busy && tr.tg.y != 0u;
+      const unsigned long long m = __ballot(has);
+      if (m == 0ull) break;
+      if ((uint32_t)__popcll(m) * PT_POSTPONE_DEN < n_busy * PT_POSTPONE_NUM) {
+        if (has) { stk[tr.sp * 64] = tr.tg; ++tr.sp; tr.tg.y = 0u; }   // postpone: too few lanes have triangle work
+        break;
+      }
+      if (has) {
+        tr.tri_step(tris);
+        if (COUNT) ++n_tris;
+      }
+    }
+    if (busy && !tr.has_node_work()) {
+      if (tr.sp == 0) {
+        HitRec hr = tr.best;
+        if (hr.prim == 0xFFFFFFFFu) hr.t = -1.0f;
+        hits[ray_i] = make_float4(hr.t, hr.u, hr.v, __uint_as_float(hr.prim));
+        busy = false;
+      } else {
+        --tr.sp;
+        tr.ng = stk[tr.sp * 64];
+      }
     }
   }
   if (COUNT) {
@@ -113,7 +228,7 @@ __global__ void __launch_bounds__(256) k_extend(const uint4* __restrict__ nodes,
 }
 
 // ------------------------------------------------------------------------------------------------ shade
-__global__ void __launch_bounds__(256) k_shade(PtRtConsts c, DeviceScene sc, const float4* __restrict__ ray_o_in,
+__global__ void __launch_bounds__(PT_SHADE_THREADS) k_shade(PtRtConsts c, DeviceScene sc, const float4* __restrict__ ray_o_in,
                                                const float4* __restrict__ ray_d_in, const uint32_t* __restrict__ qid_in,
                                                const float4* __restrict__ hits, float4* __restrict__ st_T,
                                                float4* __restrict__ st_L, float4* __restrict__ ray_o_out,
@@ -121,15 +236,15 @@ __global__ void __launch_bounds__(256) k_shade(PtRtConsts c, DeviceScene sc, con
                                                float4* __restrict__ sky_o, float4* __restrict__ sky_d,
                                                uint32_t* __restrict__ counters, int bounce, uint32_t w, uint32_t h,
                                                uint32_t first_sample) {
-  const uint32_t n = counters[CTR_QCOUNT0 + bounce];
+  const uint32_t n = counters[CTR_AT(CTR_QCOUNT0 + bounce)];
+  __shared__ BlockAppendLds s_app;
   const uint32_t lane = threadIdx.x & 63u;
-  const uint32_t wave_global = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const uint32_t waves_total = (gridDim.x * blockDim.x) >> 6;
   const bool last_bounce = (uint32_t)bounce >= c.myMaxRecursionDepth;
   const uint32_t wh = w * h;
-  uint32_t shaded_local = 0u;
-  for (uint32_t j0 = wave_global * 64u; j0 < n; j0 += waves_total * 64u) {  // wave-uniform trip count
-    const uint32_t j = j0 + lane;
+  uint32_t shaded_local = 0u, miss_local = 0u;
+  int parity = 0;
+  for (uint32_t j0 = blockIdx.x * blockDim.x; j0 < n; j0 += gridDim.x * blockDim.x, parity ^= 1) {  // block-uniform trip count
+    const uint32_t j = j0 + threadIdx.x;
     const bool active = j < n;
     bool want_ray = false, want_sky = false;
     uint32_t pid = 0u;
@@ -142,6 +257,7 @@ __global__ void __launch_bounds__(256) k_shade(PtRtConsts c, DeviceScene sc, con
       const uint32_t prim = __float_as_uint(hr.w);
       if (prim == 0xFFFFFFFFu) {
         // miss: PathTracing.hlsl:73-77
+        ++miss_local;
         if (c.mySampleSky) {
           want_sky = true;
         } else {
@@ -210,29 +326,33 @@ __global__ void __launch_bounds__(256) k_shade(PtRtConsts c, DeviceScene sc, con
         }
       }
     }
-    // compaction (all 64 lanes take part)
-    const uint32_t slot = wave_append(&counters[CTR_QCOUNT0 + bounce + 1], want_ray);
+    // compaction (every thread of the block takes part)
+    uint32_t slot, sslot;
+    block_append2(s_app, parity, &counters[CTR_AT(CTR_QCOUNT0 + bounce + 1)], want_ray, &counters[CTR_AT(CTR_SKY)], want_sky, slot, sslot);
     if (want_ray) {
       ray_o_out[slot] = make_float4(newOrigin.x, newOrigin.y, newOrigin.z, 0.001f);  // TMin 0.001 (:127)
       ray_d_out[slot] = make_float4(newDir.x, newDir.y, newDir.z, 10000.0f);
       qid_out[slot] = pid;
     }
-    const uint32_t sslot = wave_append(&counters[CTR_SKY], want_sky);
     if (want_sky) {
       sky_o[sslot] = make_float4(origin.x, origin.y, origin.z, __uint_as_float(pid));
       sky_d[sslot] = make_float4(dir.x, dir.y, dir.z, 0.0f);
     }
   }
   // one atomic per wave for the statistics
-  for (int off = 32; off > 0; off >>= 1) shaded_local += (uint32_t)__shfl_down((int)shaded_local, off);
-  if (lane == 0u && shaded_local) atomicAdd(&counters[CTR_SHADED], shaded_local);
+  for (int off = 32; off > 0; off >>= 1) {
+    shaded_local += (uint32_t)__shfl_down((int)shaded_local, off);
+    miss_local += (uint32_t)__shfl_down((int)miss_local, off);
+  }
+  if (lane == 0u && shaded_local) atomicAdd(&counters[CTR_AT(CTR_SHADED)], shaded_local);
+  if (lane == 0u && miss_local) atomicAdd(&counters[CTR_AT(CTR_MISS)], miss_local);
 }
 
 // ------------------------------------------------------------------------------------------------ sky
 __global__ void __launch_bounds__(256) k_sky(PtRtConsts c, const uint2* __restrict__ lut, const float4* __restrict__ sky_o,
                                              const float4* __restrict__ sky_d, const float4* __restrict__ st_T,
                                              float4* __restrict__ st_L, const uint32_t* __restrict__ counters) {
-  const uint32_t n = counters[CTR_SKY];
+  const uint32_t n = counters[CTR_AT(CTR_SKY)];
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     const float4 o = sky_o[i], d = sky_d[i];
     const uint32_t pid = __float_as_uint(o.w);
@@ -253,10 +373,14 @@ __global__ void __launch_bounds__(256) k_resolve(const float4* __restrict__ st_L
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i == 0) {
     unsigned long long rays = 0ull;
-    for (uint32_t b = 0; b < num_bounces; ++b) rays += counters[CTR_QCOUNT0 + b];
+    for (uint32_t b = 0; b < num_bounces; ++b) {
+      const unsigned long long q = counters[CTR_AT(CTR_QCOUNT0 + b)];
+      rays += q;
+      stats[ST_RAYS_BOUNCE0 + b] += q;
+    }
     stats[ST_RAYS] += rays;
-    stats[ST_SHADED] += counters[CTR_SHADED];
-    stats[ST_SKY] += counters[CTR_SKY];
+    stats[ST_SHADED] += counters[CTR_AT(CTR_SHADED)];
+    stats[ST_SKY] += counters[CTR_AT(CTR_MISS)];
     stats[ST_SAMPLES] += (unsigned long long)wh * samples;
   }
   if (i >= wh) return;
@@ -356,9 +480,15 @@ int extend_occupancy_blocks(uint32_t stack_entries) {
   return nb;
 }
 
+static size_t g_extend_lds_granted = 0;
 void launch_extend(const DeviceScene& sc, const float4* ray_o, const float4* ray_d, uint32_t stride, float4* hits, const uint32_t* count,
                    uint32_t* work_cursor, unsigned long long* stats, bool count_traversal, const LaunchCfg& cfg, hipStream_t s) {
   const size_t lds = extend_lds_bytes(sc.stack_entries);
+  if (lds > 64 * 1024 && lds > g_extend_lds_granted) {   // deep BVHs: opt in to more than the default dynamic-LDS limit
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_extend<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_extend<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    g_extend_lds_granted = lds;
+  }
   if (count_traversal)
     hipLaunchKernelGGL(k_extend<true>, dim3(cfg.extend_blocks), dim3(256), lds, s, sc.nodes, sc.tris, ray_o, ray_d, hits, count,
                        work_cursor, stats, sc.stack_entries, stride);
@@ -370,7 +500,11 @@ void launch_extend(const DeviceScene& sc, const float4* ray_o, const float4* ray
 void launch_shade(const PtRtConsts& c, const DeviceScene& sc, const WavefrontBuffers& wb, int bounce, uint32_t w, uint32_t h,
                   uint32_t first_sample, uint64_t max_paths, const LaunchCfg& cfg, hipStream_t s) {
   const int in = bounce & 1, out = in ^ 1;
-  hipLaunchKernelGGL(k_shade, dim3(grid_for(max_paths, cfg.stream_blocks)), dim3(256), 0, s, c, sc, wb.ray_o[in], wb.ray_d[in],
+  uint64_t g = (max_paths + PT_SHADE_THREADS - 1) / PT_SHADE_THREADS;
+  const uint64_t cap = (uint64_t)cfg.num_cus * 2u;
+  if (g > cap) g = cap;
+  if (g < 1) g = 1;
+  hipLaunchKernelGGL(k_shade, dim3((unsigned)g), dim3(PT_SHADE_THREADS), 0, s, c, sc, wb.ray_o[in], wb.ray_d[in],
                      bounce == 0 ? (const uint32_t*)nullptr : wb.qid[in], wb.hits, wb.st_T, wb.st_L, wb.ray_o[out], wb.ray_d[out],
                      wb.qid[out], wb.sky_o, wb.sky_d, wb.counters, bounce, w, h, first_sample);
 }

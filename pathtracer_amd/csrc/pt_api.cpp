@@ -58,7 +58,9 @@ struct pt_ctx {
 
   // timing
   std::vector<std::pair<hipEvent_t, hipEvent_t>> extend_events, render_events, event_pool;
+  std::vector<int> extend_event_bounce;
   double extend_ms = 0.0, render_ms = 0.0;
+  double extend_ms_bounce[16] = {0};
   uint64_t extend_launches = 0;
 
   int fail(int code, const std::string& msg) {
@@ -114,12 +116,17 @@ std::pair<hipEvent_t, hipEvent_t> get_event_pair(pt_ctx* ctx) {
 
 // Fold finished event pairs into the running sums (call after the stream is synchronised).
 void collect_events(pt_ctx* ctx) {
-  for (auto& p : ctx->extend_events) {
+  for (size_t i = 0; i < ctx->extend_events.size(); ++i) {
+    auto& p = ctx->extend_events[i];
     float ms = 0.0f;
-    if (hipEventElapsedTime(&ms, p.first, p.second) == hipSuccess) ctx->extend_ms += ms;
+    if (hipEventElapsedTime(&ms, p.first, p.second) == hipSuccess) {
+      ctx->extend_ms += ms;
+      ctx->extend_ms_bounce[std::min(15, ctx->extend_event_bounce[i])] += ms;
+    }
     ctx->event_pool.push_back(p);
   }
   ctx->extend_events.clear();
+  ctx->extend_event_bounce.clear();
   for (auto& p : ctx->render_events) {
     float ms = 0.0f;
     if (hipEventElapsedTime(&ms, p.first, p.second) == hipSuccess) ctx->render_ms += ms;
@@ -178,7 +185,7 @@ int check_consts(pt_ctx* ctx, const PtRtConsts* c, bool need_sky) {
   return PT_OK;
 }
 
-void extend_one(pt_ctx* ctx, const float4* ro, const float4* rd, uint32_t stride, float4* hits, const uint32_t* count, uint32_t* cursor) {
+void extend_one(pt_ctx* ctx, const float4* ro, const float4* rd, uint32_t stride, float4* hits, const uint32_t* count, uint32_t* cursor, int bounce = 0) {
   std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
   if (ctx->time_kernels) {
     ev = get_event_pair(ctx);
@@ -189,6 +196,7 @@ void extend_one(pt_ctx* ctx, const float4* ro, const float4* rd, uint32_t stride
   if (ctx->time_kernels) {
     (void)hipEventRecord(ev.second, ctx->stream);
     ctx->extend_events.push_back(ev);
+    ctx->extend_event_bounce.push_back(bounce);
   }
 }
 
@@ -316,8 +324,8 @@ int pt_scene_create(pt_ctx* ctx, const PtMeshDesc* meshes, uint32_t num_meshes, 
   ctx->ds.vertex_uv = d_uv;
   ctx->ds.instance_material = d_im;
   ctx->ds.materials = d_mat;
-  ctx->ds.stack_entries = bvh.max_depth + 2;
-  if (extend_lds_bytes(ctx->ds.stack_entries) > 64 * 1024)
+  ctx->ds.stack_entries = 2 * bvh.max_depth + 2;   // <=1 sibling group + <=1 postponed triangle group per level
+  if (extend_lds_bytes(ctx->ds.stack_entries) > 160 * 1024)
     return ctx->fail(PT_ERR_UNSUPPORTED, "BVH deeper than the LDS traversal stack supports (" + std::to_string(bvh.max_depth) + " levels)");
   ctx->cfg.extend_blocks = ctx->cfg.num_cus * std::max(1, std::min(8, extend_occupancy_blocks(ctx->ds.stack_entries)));
 
@@ -469,7 +477,7 @@ int pt_render(pt_ctx* ctx, const PtRtConsts* consts, uint32_t width, uint32_t he
     launch_generate(*consts, ctx->wb, width, height, first_sample + done, k, ctx->stream);
     for (uint32_t b = 0; b < bounces; ++b) {
       const int in = (int)(b & 1u);
-      extend_one(ctx, ctx->wb.ray_o[in], ctx->wb.ray_d[in], 1, ctx->wb.hits, ctx->wb.counters + CTR_QCOUNT0 + b, ctx->wb.counters + CTR_WORK0 + b);
+      extend_one(ctx, ctx->wb.ray_o[in], ctx->wb.ray_d[in], 1, ctx->wb.hits, ctx->wb.counters + CTR_AT(CTR_QCOUNT0 + b), ctx->wb.counters + CTR_AT(CTR_WORK0 + b), (int)b);
       launch_shade(*consts, ctx->ds, ctx->wb, (int)b, width, height, first_sample + done, paths, ctx->cfg, ctx->stream);
     }
     if (consts->mySampleSky) launch_sky(*consts, ctx->lut, ctx->wb, paths, ctx->cfg, ctx->stream);
@@ -495,7 +503,7 @@ int pt_primary_hits(pt_ctx* ctx, const PtRtConsts* consts, uint32_t width, uint3
   if ((rc = ensure_wavefront(ctx, wh)) != PT_OK) return rc;
   PT_HIP(hipMemsetAsync(ctx->wb.counters, 0, CTR_WORDS * sizeof(uint32_t), ctx->stream));
   launch_generate(*consts, ctx->wb, width, height, sample, 1, ctx->stream);
-  extend_one(ctx, ctx->wb.ray_o[0], ctx->wb.ray_d[0], 1, ctx->wb.hits, ctx->wb.counters + CTR_QCOUNT0, ctx->wb.counters + CTR_WORK0);
+  extend_one(ctx, ctx->wb.ray_o[0], ctx->wb.ray_d[0], 1, ctx->wb.hits, ctx->wb.counters + CTR_AT(CTR_QCOUNT0), ctx->wb.counters + CTR_AT(CTR_WORK0));
   PT_HIP(hipGetLastError());
   PT_HIP(hipMemcpyAsync(hits, ctx->wb.hits, wh * sizeof(PtHit), hipMemcpyDeviceToHost, ctx->stream));
   PT_HIP(hipStreamSynchronize(ctx->stream));
@@ -510,9 +518,9 @@ int pt_trace_rays_device(pt_ctx* ctx, const PtRay* device_rays, uint64_t num_ray
   int rc;
   if ((rc = ensure_wavefront(ctx, 1)) != PT_OK) return rc;
   PT_HIP(hipMemsetAsync(ctx->wb.counters, 0, CTR_WORDS * sizeof(uint32_t), ctx->stream));
-  launch_set_count(ctx->wb.counters + CTR_QCOUNT0, (uint32_t)num_rays, ctx->stream);
+  launch_set_count(ctx->wb.counters + CTR_AT(CTR_QCOUNT0), (uint32_t)num_rays, ctx->stream);
   const float4* base = (const float4*)device_rays;  // AoS: {origin,tmin},{dir,tmax}
-  extend_one(ctx, base, base + 1, 2, (float4*)device_hits, ctx->wb.counters + CTR_QCOUNT0, ctx->wb.counters + CTR_WORK0);
+  extend_one(ctx, base, base + 1, 2, (float4*)device_hits, ctx->wb.counters + CTR_AT(CTR_QCOUNT0), ctx->wb.counters + CTR_AT(CTR_WORK0));
   PT_HIP(hipGetLastError());
   return PT_OK;
 }
@@ -573,7 +581,9 @@ int pt_stats_get(pt_ctx* ctx, PtStats* out) {
     out->sky_misses = h[ST_SKY];
     out->nodes_visited = h[ST_NODES];
     out->tris_tested = h[ST_TRIS];
+    for (int b = 0; b < 64; ++b) out->rays_bounce[std::min(15, b)] += h[ST_RAYS_BOUNCE0 + b];
   }
+  for (int b = 0; b < 16; ++b) out->extend_ms_bounce[b] = ctx->extend_ms_bounce[b];
   out->extend_launches = ctx->extend_launches;
   out->extend_ms = ctx->extend_ms;
   out->render_ms = ctx->render_ms;
@@ -587,6 +597,7 @@ int pt_stats_reset(pt_ctx* ctx) {
   ctx->extend_ms = 0.0;
   ctx->render_ms = 0.0;
   ctx->extend_launches = 0;
+  for (int b = 0; b < 16; ++b) ctx->extend_ms_bounce[b] = 0.0;
   if (ctx->wb.stats) PT_HIP(hipMemset(ctx->wb.stats, 0, ST_WORDS * sizeof(unsigned long long)));
   return PT_OK;
 }

@@ -80,101 +80,99 @@ struct TriTester {
 
 __device__ __forceinline__ float safe_dir(float d) { return fabsf(d) < 1e-25f ? copysignf(1e-25f, d) : d; }
 
-// Closest hit. `stk` points at this lane's slot of entry 0 of the wave's LDS stack; consecutive entries are
-// 64 slots apart (lane-contiguous, conflict-free ds_read_b64/ds_write_b64).
-template <bool COUNT>
-__device__ __forceinline__ HitRec trace_closest(const uint4* __restrict__ nodes, const uint4* __restrict__ tris,
-                                                const TraceRay& ray, uint2* stk, uint32_t& n_nodes, uint32_t& n_tris) {
-  HitRec best;
-  best.t = ray.tmax; best.u = 0.0f; best.v = 0.0f; best.prim = 0xFFFFFFFFu;
+// Per-lane traversal state of one ray. The wave-level loop that drives it (replenishing finished lanes, postponing
+// sparse triangle work) lives in k_extend; this struct holds what one lane carries between loop iterations.
+struct Traverser {
+  TraceRay ray;
   TriTester tt;
-  tt.init(ray);
-  const float sdx = safe_dir(ray.dx), sdy = safe_dir(ray.dy), sdz = safe_dir(ray.dz);
-  const float idx = 1.0f / sdx, idy = 1.0f / sdy, idz = 1.0f / sdz;
-  const bool negx = sdx < 0.0f, negy = sdy < 0.0f, negz = sdz < 0.0f;
-  const uint32_t oct = (negx ? 1u : 0u) | (negy ? 2u : 0u) | (negz ? 4u : 0u);
-  const uint32_t oct4 = oct * 0x01010101u;
+  HitRec best;
+  float idx, idy, idz;
+  uint32_t oct;       // bit a set <=> direction component a is negative
+  uint2 ng;           // pending node group: x = child_base, y = hit bits (top 8, by octant priority) | imask
+  uint2 tg;           // pending triangle group: x = tri_base, y = triangle bits (low 24)
+  int sp;
 
-  uint2 ng = make_uint2(0u, 0x80000000u);  // root: one pending internal "child" at priority 7 of a group with base 0
-  uint2 tg = make_uint2(0u, 0u);
-  int sp = 0;
-  for (;;) {
-    if (ng.y > 0x00FFFFFFu) {
-      const uint32_t hits = ng.y;
-      const int b = 31 - __clz((int)hits);
-      ng.y &= ~(1u << b);
-      if (ng.y > 0x00FFFFFFu) { stk[sp * 64] = ng; ++sp; }
-      const uint32_t slot = ((uint32_t)b - 24u) ^ oct;
-      const uint32_t rel = __popc(hits & ~(0xFFFFFFFFu << slot));
-      const uint4* np = nodes + (size_t)(ng.x + rel) * 5;
-      const uint4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3], n4 = np[4];
-      if (COUNT) ++n_nodes;
+  __device__ __forceinline__ void init(const TraceRay& r) {
+    ray = r;
+    best.t = r.tmax; best.u = 0.0f; best.v = 0.0f; best.prim = 0xFFFFFFFFu;
+    tt.init(r);
+    const float sdx = safe_dir(r.dx), sdy = safe_dir(r.dy), sdz = safe_dir(r.dz);
+    idx = 1.0f / sdx; idy = 1.0f / sdy; idz = 1.0f / sdz;
+    oct = (sdx < 0.0f ? 1u : 0u) | (sdy < 0.0f ? 2u : 0u) | (sdz < 0.0f ? 4u : 0u);
+    ng = make_uint2(0u, 0x80000000u);  // root: one pending internal "child" at priority 7 of a group with base 0
+    tg = make_uint2(0u, 0u);
+    sp = 0;
+  }
 
-      const uint32_t e = n0.w;
-      const float ax = __uint_as_float((e & 0xffu) << 23) * idx;
-      const float ay = __uint_as_float(((e >> 8) & 0xffu) << 23) * idy;
-      const float az = __uint_as_float(((e >> 16) & 0xffu) << 23) * idz;
-      const float bx = (__uint_as_float(n0.x) - ray.ox) * idx;
-      const float by = (__uint_as_float(n0.y) - ray.oy) * idy;
-      const float bz = (__uint_as_float(n0.z) - ray.oz) * idz;
+  __device__ __forceinline__ bool has_node_work() const { return ng.y > 0x00FFFFFFu; }
 
-      uint32_t hitmask = 0u;
+  // Pops the nearest pending internal child, fetches its 80-byte node (5 x 128-bit loads) and intersects the 8
+  // quantised child boxes. `stk` = this lane's slot of stack entry 0; entries are 64 slots apart.
+  __device__ __forceinline__ void node_step(const uint4* __restrict__ nodes, uint2* stk) {
+    const uint32_t hits = ng.y;
+    const int b = 31 - __clz((int)hits);
+    ng.y &= ~(1u << b);
+    if (ng.y > 0x00FFFFFFu) { stk[sp * 64] = ng; ++sp; }
+    const uint32_t slot = ((uint32_t)b - 24u) ^ oct;
+    const uint32_t rel = __popc(hits & ~(0xFFFFFFFFu << slot));
+    const uint4* np = nodes + (size_t)(ng.x + rel) * 5;
+    const uint4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3], n4 = np[4];
+
+    const uint32_t e = n0.w;
+    const float ax = __uint_as_float((e & 0xffu) << 23) * idx;
+    const float ay = __uint_as_float(((e >> 8) & 0xffu) << 23) * idy;
+    const float az = __uint_as_float(((e >> 16) & 0xffu) << 23) * idz;
+    const float bx = (__uint_as_float(n0.x) - ray.ox) * idx;
+    const float by = (__uint_as_float(n0.y) - ray.oy) * idy;
+    const float bz = (__uint_as_float(n0.z) - ray.oz) * idz;
+    const bool negx = (oct & 1u) != 0u, negy = (oct & 2u) != 0u, negz = (oct & 4u) != 0u;
+    const uint32_t oct4 = oct * 0x01010101u;
+
+    uint32_t hitmask = 0u;
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const uint32_t meta4 = h ? n1.w : n1.z;
-        const uint32_t qlx = h ? n2.y : n2.x, qly = h ? n2.w : n2.z, qlz = h ? n3.y : n3.x;
-        const uint32_t qhx = h ? n3.w : n3.z, qhy = h ? n4.y : n4.x, qhz = h ? n4.w : n4.z;
-        const uint32_t nx = negx ? qhx : qlx, fx = negx ? qlx : qhx;
-        const uint32_t ny = negy ? qhy : qly, fy = negy ? qly : qhy;
-        const uint32_t nz = negz ? qhz : qlz, fz = negz ? qlz : qhz;
-        const uint32_t is_inner4 = (meta4 & (meta4 << 1)) & 0x10101010u;
-        const uint32_t inner_mask4 = (is_inner4 >> 4) * 0xffu;
-        const uint32_t bit_index4 = (meta4 ^ (oct4 & inner_mask4)) & 0x1f1f1f1fu;
-        const uint32_t child_bits4 = (meta4 >> 5) & 0x07070707u;
+    for (int h = 0; h < 2; ++h) {
+      const uint32_t meta4 = h ? n1.w : n1.z;
+      const uint32_t qlx = h ? n2.y : n2.x, qly = h ? n2.w : n2.z, qlz = h ? n3.y : n3.x;
+      const uint32_t qhx = h ? n3.w : n3.z, qhy = h ? n4.y : n4.x, qhz = h ? n4.w : n4.z;
+      const uint32_t nx = negx ? qhx : qlx, fx = negx ? qlx : qhx;
+      const uint32_t ny = negy ? qhy : qly, fy = negy ? qly : qhy;
+      const uint32_t nz = negz ? qhz : qlz, fz = negz ? qlz : qhz;
+      const uint32_t is_inner4 = (meta4 & (meta4 << 1)) & 0x10101010u;
+      const uint32_t inner_mask4 = (is_inner4 >> 4) * 0xffu;
+      const uint32_t bit_index4 = (meta4 ^ (oct4 & inner_mask4)) & 0x1f1f1f1fu;
+      const uint32_t child_bits4 = (meta4 >> 5) & 0x07070707u;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float tnx = __builtin_fmaf((float)((nx >> (8 * j)) & 0xffu), ax, bx);
-          const float tny = __builtin_fmaf((float)((ny >> (8 * j)) & 0xffu), ay, by);
-          const float tnz = __builtin_fmaf((float)((nz >> (8 * j)) & 0xffu), az, bz);
-          const float tfx = __builtin_fmaf((float)((fx >> (8 * j)) & 0xffu), ax, bx);
-          const float tfy = __builtin_fmaf((float)((fy >> (8 * j)) & 0xffu), ay, by);
-          const float tfz = __builtin_fmaf((float)((fz >> (8 * j)) & 0xffu), az, bz);
-          const float tn = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, ray.tmin));
-          const float tf = fminf(fminf(tfx, tfy), fminf(tfz, best.t));
-          // conservative: widen by ~8 ulp so fp32 rounding of the slab arithmetic can never cull a true hit
-          if (tn <= tf * 1.000001f) {
-            const uint32_t cb = (child_bits4 >> (8 * j)) & 0xffu;
-            const uint32_t bi = (bit_index4 >> (8 * j)) & 0xffu;
-            hitmask |= cb << bi;
-          }
+      for (int j = 0; j < 4; ++j) {
+        const float tnx = __builtin_fmaf((float)((nx >> (8 * j)) & 0xffu), ax, bx);
+        const float tny = __builtin_fmaf((float)((ny >> (8 * j)) & 0xffu), ay, by);
+        const float tnz = __builtin_fmaf((float)((nz >> (8 * j)) & 0xffu), az, bz);
+        const float tfx = __builtin_fmaf((float)((fx >> (8 * j)) & 0xffu), ax, bx);
+        const float tfy = __builtin_fmaf((float)((fy >> (8 * j)) & 0xffu), ay, by);
+        const float tfz = __builtin_fmaf((float)((fz >> (8 * j)) & 0xffu), az, bz);
+        const float tn = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, ray.tmin));
+        const float tf = fminf(fminf(tfx, tfy), fminf(tfz, best.t));
+        // conservative: widen by ~8 ulp so fp32 rounding of the slab arithmetic can never cull a true hit
+        if (tn <= tf * 1.000001f) {
+          const uint32_t cb = (child_bits4 >> (8 * j)) & 0xffu;
+          const uint32_t bi = (bit_index4 >> (8 * j)) & 0xffu;
+          hitmask |= cb << bi;
         }
       }
-      ng.x = n1.x;
-      ng.y = (hitmask & 0xFF000000u) | (e >> 24);
-      tg.x = n1.y;
-      tg.y = hitmask & 0x00FFFFFFu;
-    } else {
-      tg = ng;
-      ng = make_uint2(0u, 0u);
     }
-
-    while (tg.y != 0u) {
-      const int i = __ffs((int)tg.y) - 1;
-      tg.y &= tg.y - 1u;
-      const uint4* tp = tris + (size_t)(tg.x + (uint32_t)i) * 3;
-      const uint4 q0 = tp[0], q1 = tp[1], q2 = tp[2];
-      if (COUNT) ++n_tris;
-      tt.test(q0, q1, q2, ray.tmin, best);
-    }
-
-    if (ng.y <= 0x00FFFFFFu) {
-      if (sp == 0) break;
-      --sp;
-      ng = stk[sp * 64];
-    }
+    ng.x = n1.x;
+    ng.y = (hitmask & 0xFF000000u) | (e >> 24);
+    tg.x = n1.y;
+    tg.y = hitmask & 0x00FFFFFFu;
   }
-  if (best.prim == 0xFFFFFFFFu) best.t = -1.0f;
-  return best;
-}
+
+  // Tests the lowest pending triangle of tg.
+  __device__ __forceinline__ void tri_step(const uint4* __restrict__ tris) {
+    const int i = __ffs((int)tg.y) - 1;
+    tg.y &= tg.y - 1u;
+    const uint4* tp = tris + (size_t)(tg.x + (uint32_t)i) * 3;
+    const uint4 q0 = tp[0], q1 = tp[1], q2 = tp[2];
+    tt.test(q0, q1, q2, ray.tmin, best);
+  }
+};
 
 }  // namespace ptd

@@ -320,7 +320,7 @@ def street(seed=2, target_tris=3145728):
         while x < 120.0:
             wdt = 14.0 + 10.0 * float(_rand01(seed, 10, k))
             hgt = 10.0 + 18.0 * float(_rand01(seed, 11, k))
-            m = _building_block(seed + 50 + k, x, x + wdt, z0, z1, hgt, 192, 160)
+            m = _building_block(seed + 50 + k, x, x + wdt, z0, z1, hgt, 112, 96)
             add(m, k)
             total += len(m[1]) // 3
             x += wdt + 1.0
@@ -361,7 +361,7 @@ def courtyard(seed=3, target_tris=10485760):
         add(m, k)
         total += len(m[1]) // 3
     # trees: trunk + a cloud of small leaf quads (2 triangles each)
-    n_trees, leaves_per_tree = 24, 120000
+    n_trees, leaves_per_tree = 24, 100000
     for t in range(n_trees):
         cx = -30.0 + 60.0 * float(_rand01(seed, 20, t))
         cz = -22.0 + 44.0 * float(_rand01(seed, 21, t))
