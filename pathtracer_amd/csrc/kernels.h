@@ -51,6 +51,9 @@ struct LaunchCfg {
   int num_cus = 256;
   int extend_blocks = 1024;   // persistent grid of the extend kernel
   int stream_blocks = 2048;   // grid cap of the grid-stride kernels
+  uint32_t fetch_min = 16;    // extend: refill idle lanes once this many of the 64 are idle
+  uint32_t postpone_pct = 35; // extend: postpone triangle tests while fewer than this % of busy lanes have any
+  int extend_blocks_per_cu = 0; // 0 = from the occupancy query
 };
 
 void launch_transmittance_lut(const PtAtmosphere& atm, uint2* lut, hipStream_t s);

@@ -116,24 +116,16 @@ __global__ void __launch_bounds__(256) k_generate(PtRtConsts c, float4* __restri
 // Persistent waves. Each wave owns a local pool of queue slots (claimed from the global cursor in chunks, one atomic
 // per chunk: a single word sustains only ~90 returning atomics/us chip-wide, so per-64-ray claims would bound the
 // kernel) and keeps its 64 lanes busy: lanes whose ray has finished are refilled from the pool once enough of them are
-// idle (FETCH_MIN), and triangle tests are postponed to the LDS stack while too few lanes have any (POSTPONE_*), so
+// idle (fetch_min), and triangle tests are postponed to the LDS stack while fewer than postpone_pct % of the busy
+// lanes have any, so
 // that the wave spends its instructions on box tests or on triangle tests with most lanes active.
-#ifndef PT_FETCH_MIN
-#define PT_FETCH_MIN 16
-#endif
-#ifndef PT_POSTPONE_NUM
-#define PT_POSTPONE_NUM 1   // postpone while (lanes with triangles) * DEN < (busy lanes) * NUM
-#endif
-#ifndef PT_POSTPONE_DEN
-#define PT_POSTPONE_DEN 4
-#endif
 
 template <bool COUNT>
 __global__ void __launch_bounds__(256) k_extend(const uint4* __restrict__ nodes, const uint4* __restrict__ tris,
                                                 const float4* __restrict__ ray_o, const float4* __restrict__ ray_d,
                                                 float4* __restrict__ hits, const uint32_t* __restrict__ count_ptr,
                                                 uint32_t* __restrict__ work_cursor, unsigned long long* __restrict__ stats,
-                                                uint32_t stack_entries, uint32_t stride) {
+                                                uint32_t stack_entries, uint32_t stride, uint32_t fetch_min, uint32_t postpone_pct) {
   extern __shared__ uint2 s_stack[];
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   uint2* stk = s_stack + (size_t)wave * stack_entries * 64u + lane;
@@ -155,7 +147,7 @@ __global__ void __launch_bounds__(256) k_extend(const uint4* __restrict__ nodes,
     const unsigned long long idle_mask = __ballot(!busy);
     const uint32_t n_idle = (uint32_t)__popcll(idle_mask);
     if (n_idle == 64u && exhausted) break;
-    if (!exhausted && (n_idle >= PT_FETCH_MIN)) {
+    if (!exhausted && (n_idle >= fetch_min)) {
       if (pool_next >= pool_end) {
         uint32_t base = 0u;
         if (lane == 0u) base = atomicAdd(work_cursor, chunk);
@@ -200,7 +192,7 @@ __global__ void __launch_bounds__(256) k_extend(const uint4* __restrict__ nodes,
       const bool has = busy && tr.tg.y != 0u;
       const unsigned long long m = __ballot(has);
       if (m == 0ull) break;
-      if ((uint32_t)__popcll(m) * PT_POSTPONE_DEN < n_busy * PT_POSTPONE_NUM) {
+      if ((uint32_t)__popcll(m) * 100u < n_busy * postpone_pct) {
         if (has) { stk[tr.sp * 64] = tr.tg; ++tr.sp; tr.tg.y = 0u; }   // postpone: too few lanes have triangle work
         break;
       }
@@ -491,10 +483,10 @@ void launch_extend(const DeviceScene& sc, const float4* ray_o, const float4* ray
   }
   if (count_traversal)
     hipLaunchKernelGGL(k_extend<true>, dim3(cfg.extend_blocks), dim3(256), lds, s, sc.nodes, sc.tris, ray_o, ray_d, hits, count,
-                       work_cursor, stats, sc.stack_entries, stride);
+                       work_cursor, stats, sc.stack_entries, stride, cfg.fetch_min, cfg.postpone_pct);
   else
     hipLaunchKernelGGL(k_extend<false>, dim3(cfg.extend_blocks), dim3(256), lds, s, sc.nodes, sc.tris, ray_o, ray_d, hits, count,
-                       work_cursor, stats, sc.stack_entries, stride);
+                       work_cursor, stats, sc.stack_entries, stride, cfg.fetch_min, cfg.postpone_pct);
 }
 
 void launch_shade(const PtRtConsts& c, const DeviceScene& sc, const WavefrontBuffers& wb, int bounce, uint32_t w, uint32_t h,

@@ -276,6 +276,20 @@ int pt_set_option(pt_ctx* ctx, int option, int64_t value) {
       if (value != 0) return ctx->fail(PT_ERR_UNSUPPORTED, "only sky mode 0 (ray-march on every miss) is implemented");
       ctx->sky_mode = 0;
       return PT_OK;
+    case PT_OPT_EXTEND_FETCH_MIN:
+      if (value < 1 || value > 64) return ctx->fail(PT_ERR_INVALID_ARG, "fetch_min must be 1..64");
+      ctx->cfg.fetch_min = (uint32_t)value;
+      return PT_OK;
+    case PT_OPT_EXTEND_POSTPONE_PCT:
+      if (value < 0 || value > 100) return ctx->fail(PT_ERR_INVALID_ARG, "postpone_pct must be 0..100");
+      ctx->cfg.postpone_pct = (uint32_t)value;
+      return PT_OK;
+    case PT_OPT_EXTEND_BLOCKS_PER_CU:
+      if (value < 0 || value > 16) return ctx->fail(PT_ERR_INVALID_ARG, "blocks per CU must be 0..16");
+      ctx->cfg.extend_blocks_per_cu = (int)value;
+      if (ctx->has_scene)
+        ctx->cfg.extend_blocks = ctx->cfg.num_cus * (value > 0 ? (int)value : std::max(1, std::min(8, extend_occupancy_blocks(ctx->ds.stack_entries))));
+      return PT_OK;
     default: return ctx->fail(PT_ERR_INVALID_ARG, "unknown option");
   }
 }
@@ -327,7 +341,7 @@ int pt_scene_create(pt_ctx* ctx, const PtMeshDesc* meshes, uint32_t num_meshes, 
   ctx->ds.stack_entries = 2 * bvh.max_depth + 2;   // <=1 sibling group + <=1 postponed triangle group per level
   if (extend_lds_bytes(ctx->ds.stack_entries) > 160 * 1024)
     return ctx->fail(PT_ERR_UNSUPPORTED, "BVH deeper than the LDS traversal stack supports (" + std::to_string(bvh.max_depth) + " levels)");
-  ctx->cfg.extend_blocks = ctx->cfg.num_cus * std::max(1, std::min(8, extend_occupancy_blocks(ctx->ds.stack_entries)));
+  ctx->cfg.extend_blocks = ctx->cfg.num_cus * (ctx->cfg.extend_blocks_per_cu > 0 ? ctx->cfg.extend_blocks_per_cu : std::max(1, std::min(8, extend_occupancy_blocks(ctx->ds.stack_entries))));
 
   PtSceneInfo& in = ctx->info;
   in.num_triangles = fs.num_triangles();
