@@ -1,0 +1,343 @@
+// PathTracerHost.cpp — see PathTracerHost.h. Reference: PathTracer/PathTracer.cpp, PathTracer/Sky.cpp.
+#include "PathTracerHost.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <map>
+#include <sstream>
+#include <tuple>
+
+namespace pth {
+
+static float3 sub(float3 a, float3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+static float3 add(float3 a, float3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+static float3 mul(float3 a, float s) { return {a.x * s, a.y * s, a.z * s}; }
+static float3 cross(float3 a, float3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+static float3 norm(float3 a) { float l = std::sqrt(a.x * a.x + a.y * a.y + a.z * a.z); return {a.x / l, a.y / l, a.z / l}; }
+
+uint32_t Encode_Unorm_RGBA(const float c[4]) {
+  uint32_t r = 0;
+  for (int k = 0; k < 4; ++k) {
+    float v = std::min(std::max(c[k], 0.0f), 1.0f);
+    r |= (uint32_t)std::floor(v * 255.0f + 0.5f) << (8 * k);
+  }
+  return r;
+}
+
+// ------------------------------------------------------------------------------------------------ OBJ / MTL
+static std::map<std::string, MaterialDesc> ParseMtl(const std::string& aPath, std::vector<std::string>& anOrderOut) {
+  std::map<std::string, MaterialDesc> mats;
+  std::ifstream f(aPath);
+  std::string line, cur;
+  while (std::getline(f, line)) {
+    std::istringstream ss(line);
+    std::string t;
+    ss >> t;
+    if (t == "newmtl") { ss >> cur; mats[cur] = MaterialDesc(); anOrderOut.push_back(cur); }
+    else if (!cur.empty() && t == "Kd") { ss >> mats[cur].myColor[0] >> mats[cur].myColor[1] >> mats[cur].myColor[2]; }
+    else if (!cur.empty() && t == "Ke") { ss >> mats[cur].myEmission[0] >> mats[cur].myEmission[1] >> mats[cur].myEmission[2]; }
+  }
+  return mats;
+}
+
+bool ImportObj(const std::string& aPath, SceneData& out, std::string* err) {
+  std::ifstream f(aPath);
+  if (!f) { if (err) *err = "cannot open " + aPath; return false; }
+  std::vector<float3> pos, nrm;
+  std::vector<std::array<float, 2>> tex;
+  std::map<std::string, MaterialDesc> mtl;
+  std::vector<std::string> matOrder;
+  struct Group { std::string mat; std::vector<std::array<std::array<int, 3>, 3>> faces; };
+  std::vector<Group> groups;
+  bool open = false;
+  std::string curMat, line;
+  const std::string dir = aPath.find_last_of("/\\") == std::string::npos ? "" : aPath.substr(0, aPath.find_last_of("/\\") + 1);
+  while (std::getline(f, line)) {
+    std::istringstream ss(line);
+    std::string t;
+    ss >> t;
+    if (t == "v") { float3 p; ss >> p.x >> p.y >> p.z; pos.push_back(p); }
+    else if (t == "vn") { float3 p; ss >> p.x >> p.y >> p.z; nrm.push_back(p); }
+    else if (t == "vt") { std::array<float, 2> p{{0, 0}}; ss >> p[0] >> p[1]; tex.push_back(p); }
+    else if (t == "mtllib") { std::string n; ss >> n; auto m = ParseMtl(dir + n, matOrder); mtl.insert(m.begin(), m.end()); }
+    else if (t == "o" || t == "g") { open = false; }
+    else if (t == "usemtl") { ss >> curMat; open = false; }
+    else if (t == "f") {
+      if (!open) { groups.push_back(Group{curMat, {}}); open = true; }
+      std::vector<std::array<int, 3>> corners;
+      std::string c;
+      while (ss >> c) {
+        std::array<int, 3> k{{0, 0, 0}};
+        int part = 0;
+        std::string num;
+        for (size_t i = 0; i <= c.size(); ++i) {
+          if (i == c.size() || c[i] == '/') { if (!num.empty() && part < 3) k[part] = std::stoi(num); num.clear(); ++part; }
+          else num.push_back(c[i]);
+        }
+        k[0] = k[0] > 0 ? k[0] - 1 : (int)pos.size() + k[0];
+        k[1] = k[1] > 0 ? k[1] - 1 : (k[1] < 0 ? (int)tex.size() + k[1] : -1);
+        k[2] = k[2] > 0 ? k[2] - 1 : (k[2] < 0 ? (int)nrm.size() + k[2] : -1);
+        corners.push_back(k);
+      }
+      for (size_t i = 1; i + 1 < corners.size(); ++i) groups.back().faces.push_back({{corners[0], corners[i], corners[i + 1]}});
+    }
+  }
+  for (auto& g : groups)
+    if (!g.mat.empty() && !mtl.count(g.mat)) { mtl[g.mat] = MaterialDesc(); matOrder.push_back(g.mat); }
+  if (matOrder.empty()) { matOrder.push_back("default"); mtl["default"] = MaterialDesc(); }
+  out = SceneData();
+  for (auto& n : matOrder) out.myMaterials.push_back(mtl[n]);
+  for (auto& g : groups) {
+    MeshData m;
+    std::map<std::tuple<int, int, int>, uint32_t> vmap;
+    for (auto& tri : g.faces) {
+      float3 fn{0, 0, 1};
+      { float3 a = pos[tri[0][0]], b = pos[tri[1][0]], c = pos[tri[2][0]]; float3 n = cross(sub(b, a), sub(c, a)); float l = std::sqrt(n.x * n.x + n.y * n.y + n.z * n.z); if (l > 0) fn = mul(n, 1.0f / l); }
+      for (auto& k : tri) {
+        auto key = std::make_tuple(k[0], k[1], k[2]);
+        auto it = vmap.find(key);
+        if (it == vmap.end()) {
+          PtVertex v;
+          float3 p = pos[k[0]], n = k[2] >= 0 ? nrm[k[2]] : fn;
+          v.pos[0] = p.x; v.pos[1] = p.y; v.pos[2] = p.z;
+          v.normal[0] = n.x; v.normal[1] = n.y; v.normal[2] = n.z;
+          v.uv[0] = k[1] >= 0 ? tex[k[1]][0] : 0.0f; v.uv[1] = k[1] >= 0 ? tex[k[1]][1] : 0.0f;
+          it = vmap.emplace(key, (uint32_t)m.myVertexData.size()).first;
+          m.myVertexData.push_back(v);
+        }
+        m.myIndexData.push_back(it->second);
+      }
+    }
+    SceneMeshInstance inst;
+    inst.myMeshIndex = (uint32_t)out.myMeshes.size();
+    auto mi = std::find(matOrder.begin(), matOrder.end(), g.mat);
+    inst.myMaterialIndex = mi == matOrder.end() ? 0u : (uint32_t)(mi - matOrder.begin());
+    out.myMeshes.push_back(std::move(m));
+    out.myInstances.push_back(inst);
+  }
+  return true;
+}
+
+// ------------------------------------------------------------------------------------------------ Camera
+void Camera::LookAt(float3 eye, float3 target, float3 up) {
+  float3 f = norm(sub(target, eye)), r = norm(cross(up, f)), u = cross(f, r);
+  myPosition = eye;
+  const float3 rows[3] = {r, u, f};
+  for (int i = 0; i < 3; ++i) { myOrientation[i][0] = rows[i].x; myOrientation[i][1] = rows[i].y; myOrientation[i][2] = rows[i].z; }
+}
+
+void Camera::GetVerticesOnNearPlane(float3 v[4]) const {
+  const float3 right{myOrientation[0][0], myOrientation[0][1], myOrientation[0][2]};
+  const float3 up{myOrientation[1][0], myOrientation[1][1], myOrientation[1][2]};
+  const float3 fwd{myOrientation[2][0], myOrientation[2][1], myOrientation[2][2]};
+  const float halfH = (float)(myNear * std::tan(myFovDeg * 3.14159265358979323846 / 180.0 * 0.5));
+  const float halfW = halfH * (myWidth / myHeight);
+  const float3 c = add(myPosition, mul(fwd, myNear));
+  v[0] = sub(sub(c, mul(right, halfW)), mul(up, halfH));
+  v[1] = sub(add(c, mul(right, halfW)), mul(up, halfH));
+  v[2] = add(add(c, mul(right, halfW)), mul(up, halfH));
+  v[3] = add(sub(c, mul(right, halfW)), mul(up, halfH));
+}
+
+// ------------------------------------------------------------------------------------------------ Sky
+void SetupEarthAtmosphere(PtAtmosphere& p) {
+  const float EarthBottomRadius = 6360000.0f, EarthTopRadius = 6460000.0f;
+  const float EarthRayleighScaleHeight = 8000.0f, EarthMieScaleHeight = 1200.0f;
+  const float rs[3] = {0.000005802f, 0.000013558f, 0.000033100f}, ae[3] = {0.000000650f, 0.000001881f, 0.0000000085f};
+  for (int i = 0; i < 3; ++i) {
+    p.RayleighScattering[i] = rs[i];
+    p.AbsorptionExtinction[i] = ae[i];
+    p.GroundAlbedo[i] = 0.0f;
+    p.MieScattering[i] = 0.000003996f;
+    p.MieExtinction[i] = 0.000004440f;
+    p.MieAbsorption[i] = std::max(0.0f, p.MieExtinction[i] - p.MieScattering[i]);
+  }
+  p.RayleighDensityExpScale = -1.0f / EarthRayleighScaleHeight;
+  p.BottomRadius = EarthBottomRadius;
+  p.TopRadius = EarthTopRadius;
+  p.MieDensityExpScale = -1.0f / EarthMieScaleHeight;
+  p.MiePhaseG = 0.8f;
+  p.AbsorptionDensity0LayerWidth = 25000.0f;
+  p.AbsorptionDensity0ConstantTerm = -2.0f / 3.0f;
+  p.AbsorptionDensity0LinearTerm = 1.0f / 15.0f;
+  p.AbsorptionDensity1ConstantTerm = 8.0f / 3.0f;
+  p.AbsorptionDensity1LinearTerm = -1.0f / 15.0f;
+}
+
+Sky::Sky(pt_ctx* aCtx) : myCtx(aCtx) { SetupEarthAtmosphere(myAtmosphereParams); }
+void Sky::ComputeTranmittanceLut() {
+  int rc = pt_sky_set(myCtx, &myAtmosphereParams);
+  if (rc != PT_OK) throw PtException(rc, pt_last_error(myCtx));
+}
+
+// ------------------------------------------------------------------------------------------------ PathTracer
+void PathTracer::Check(int rc) const {
+  if (rc != PT_OK) throw PtException(rc, pt_last_error(myCtx));
+}
+
+PathTracer::PathTracer(int aDevice, uint32_t w, uint32_t h) : myWindowWidth(w), myWindowHeight(h) {
+  int rc = pt_create(aDevice, &myCtx);
+  if (rc != PT_OK) throw PtException(rc, pt_last_error(nullptr));
+  myCamera.myWidth = (float)w;
+  myCamera.myHeight = (float)h;
+  UpdateOutputTexture();
+  InitSky();
+}
+
+PathTracer::~PathTracer() {
+  delete mySky;
+  if (myCtx) pt_destroy(myCtx);
+}
+
+void PathTracer::InitSky() {
+  delete mySky;
+  mySky = new Sky(myCtx);
+  mySkyDirty = true;
+}
+
+void PathTracer::LoadScene(const char* aPath, const float3& aCamPos) {
+  SceneData scene;
+  std::string err;
+  if (!ImportObj(aPath, scene, &err)) throw PtException(PT_ERR_INVALID_ARG, "Failed importing scene " + std::string(aPath) + ": " + err);
+  LoadScene(scene, aCamPos);
+}
+
+void PathTracer::LoadScene(const SceneData& aScene, const float3& aCamPos) {
+  InitRtScene(aScene);
+  myCamera = Camera();
+  myCamera.myPosition = aCamPos;
+  myCamera.myFovDeg = 60.0f;
+  myCamera.myNear = 1.0f;
+  myCamera.myFar = 10000.0f;
+  myCamera.myWidth = (float)myWindowWidth;
+  myCamera.myHeight = (float)myWindowHeight;
+  RestartAccumulation();
+}
+
+void PathTracer::InitRtScene(const SceneData& aScene) {
+  std::vector<PtMeshDesc> meshes(aScene.myMeshes.size());
+  for (size_t i = 0; i < meshes.size(); ++i) {
+    meshes[i].vertices = aScene.myMeshes[i].myVertexData.data();
+    meshes[i].num_vertices = (uint32_t)aScene.myMeshes[i].myVertexData.size();
+    meshes[i].indices = aScene.myMeshes[i].myIndexData.data();
+    meshes[i].num_triangles = (uint32_t)(aScene.myMeshes[i].myIndexData.size() / 3);
+  }
+  std::vector<PtInstanceDesc> inst(aScene.myInstances.size());
+  for (size_t i = 0; i < inst.size(); ++i) {
+    inst[i].myMeshIndex = aScene.myInstances[i].myMeshIndex;
+    inst[i].myMaterialIndex = aScene.myInstances[i].myMaterialIndex;
+    memcpy(inst[i].myTransform, aScene.myInstances[i].myTransform.data(), sizeof(float) * 16);
+  }
+  std::vector<PtMaterial> mats(aScene.myMaterials.size());
+  for (size_t i = 0; i < mats.size(); ++i) {
+    memcpy(mats[i].myEmission, aScene.myMaterials[i].myEmission, sizeof(float) * 3);
+    mats[i].myColor = Encode_Unorm_RGBA(aScene.myMaterials[i].myColor);   // PathTracer.cpp:328
+  }
+  Check(pt_scene_create(myCtx, meshes.data(), (uint32_t)meshes.size(), inst.data(), (uint32_t)inst.size(), mats.data(),
+                        (uint32_t)mats.size(), PT_SCENE_DEFAULT));
+}
+
+void PathTracer::UpdateOutputTexture() {
+  uint32_t w = myWindowWidth, h = myWindowHeight;
+  if (myHalfResRender) { w = (w + 1) / 2; h = (h + 1) / 2; }
+  myOutputWidth = w;
+  myOutputHeight = h;
+  Check(pt_accum_reset(myCtx, w, h));
+  myNumAccumulationFrames = 0;
+  myAccumulationNeedsClear = false;
+}
+
+void PathTracer::RestartAccumulation() {
+  myNumAccumulationFrames = 0u;
+  myAccumulationNeedsClear = true;
+}
+
+void PathTracer::OnWindowResized(uint32_t w, uint32_t h) {
+  myWindowWidth = w;
+  myWindowHeight = h;
+  myCamera.myWidth = (float)w;
+  myCamera.myHeight = (float)h;
+  UpdateOutputTexture();
+  RestartAccumulation();
+}
+
+void PathTracer::Update() {
+  if (!myAccumulate) RestartAccumulation();   // always render frame 0 only (PathTracer.cpp:562-564)
+}
+
+PtRtConsts PathTracer::BuildRtConsts() const {
+  PtRtConsts c;
+  memset(&c, 0, sizeof(c));
+  float3 v[4];
+  myCamera.GetVerticesOnNearPlane(v);
+  auto put = [](float* d, float3 s) { d[0] = s.x; d[1] = s.y; d[2] = s.z; };
+  put(c.myNearPlaneCorner, v[0]);
+  c.myAoDistance = myAoDistance;
+  put(c.myXAxis, sub(v[1], v[0]));
+  put(c.myYAxis, sub(v[3], v[0]));
+  put(c.myCameraPos, myCamera.myPosition);
+  c.myLightInstanceId = (uint32_t)myLightInstanceIdx;
+  c.myNumHaltonSamples = 8192;
+  put(c.myLightEmission, myLightEnabled ? mul(myLightColor, myLightStrength) : float3{0, 0, 0});
+  c.mySampleSky = mySampleSky ? 1u : 0u;
+  put(c.mySkyFallbackEmission, float3{mySkyFallbackIntensity, mySkyFallbackIntensity, mySkyFallbackIntensity});
+  c.myPhongSpecularPower = myPhongSpecularPower;
+  c.myFrameRandomSeed = myNumAccumulationFrames;
+  c.myNumAccumulationFrames = myNumAccumulationFrames;
+  c.myMaxRecursionDepth = (uint32_t)myMaxRecursionDepth;
+  c.mySkyConsts.myAtmosphere = mySky->myAtmosphereParams;
+  put(c.mySkyConsts.mySunDirection, mySky->mySunDir);
+  put(c.mySkyConsts.mySunIlluminance, mySky->mySunIlluminance);
+  c.mySkyConsts.myRayMarchMinMaxSPP[0] = 4.0f;   // PathTracer.cpp:707
+  c.mySkyConsts.myRayMarchMinMaxSPP[1] = 14.0f;
+  return c;
+}
+
+void PathTracer::RenderRT(uint32_t aNumFrames) {
+  if (myAccumulationNeedsClear || !myAccumulate) {
+    Check(pt_accum_reset(myCtx, myOutputWidth, myOutputHeight));   // clear + frame counter = 0 (PathTracer.cpp:668-678)
+    myAccumulationNeedsClear = false;
+    myNumAccumulationFrames = 0;
+  }
+  if (mySampleSky && mySkyDirty) {
+    mySky->ComputeTranmittanceLut();   // PathTracer.cpp:580
+    mySkyDirty = false;
+  }
+  const PtRtConsts c = BuildRtConsts();
+  Check(pt_render(myCtx, &c, myOutputWidth, myOutputHeight, myNumAccumulationFrames, aNumFrames));
+  myNumAccumulationFrames += aNumFrames;
+}
+
+void PathTracer::ReadOutput(std::vector<float>& out) {
+  out.resize((size_t)myOutputWidth * myOutputHeight * 4);
+  Check(pt_accum_read(myCtx, out.data()));
+}
+
+void PathTracer::Tonemap(std::vector<float>& rgba) {
+  for (size_t i = 0; i + 3 < rgba.size(); i += 4) {
+    for (int k = 0; k < 3; ++k) rgba[i + k] = rgba[i + k] / (rgba[i + k] + 1.0f);
+    rgba[i + 3] = 1.0f;
+  }
+}
+
+bool PathTracer::WritePfm(const char* aPath, bool aTonemap) {
+  std::vector<float> img;
+  ReadOutput(img);
+  if (aTonemap) Tonemap(img);
+  FILE* f = fopen(aPath, "wb");
+  if (!f) return false;
+  fprintf(f, "PF\n%u %u\n-1.0\n", myOutputWidth, myOutputHeight);
+  std::vector<float> row((size_t)myOutputWidth * 3);
+  for (uint32_t y = 0; y < myOutputHeight; ++y) {   // PFM stores the bottom row first
+    const float* src = &img[(size_t)(myOutputHeight - 1 - y) * myOutputWidth * 4];
+    for (uint32_t x = 0; x < myOutputWidth; ++x) { row[3 * x] = src[4 * x]; row[3 * x + 1] = src[4 * x + 1]; row[3 * x + 2] = src[4 * x + 2]; }
+    fwrite(row.data(), sizeof(float), row.size(), f);
+  }
+  fclose(f);
+  return true;
+}
+
+}  // namespace pth

@@ -111,6 +111,29 @@ def load_obj(path):
     return SceneData(meshes, instances, materials, name=os.path.basename(path))
 
 
+def scene_to_obj(scene, path):
+    """Write a SceneData as OBJ + MTL (one group per instance, %.9g so fp32 values round-trip exactly)."""
+    mtl_path = os.path.splitext(path)[0] + ".mtl"
+    with open(mtl_path, "w") as f:
+        for k, (e, c) in enumerate(scene.materials):
+            f.write(f"newmtl m{k}\nKd {c[0]:.9g} {c[1]:.9g} {c[2]:.9g}\nKe {e[0]:.9g} {e[1]:.9g} {e[2]:.9g}\n")
+    with open(path, "w") as f:
+        f.write(f"mtllib {os.path.basename(mtl_path)}\n")
+        off = 0
+        for gi, (m, mat, t) in enumerate(scene.instances):
+            assert t is None, "OBJ export supports identity instances only"
+            v, idx = scene.meshes[m]
+            f.write(f"o g{gi}\n")
+            for p in v["pos"]:
+                f.write(f"v {p[0]:.9g} {p[1]:.9g} {p[2]:.9g}\n")
+            for n in v["normal"]:
+                f.write(f"vn {n[0]:.9g} {n[1]:.9g} {n[2]:.9g}\n")
+            f.write(f"usemtl m{mat}\n")
+            for a, b, c in idx.reshape(-1, 3) + 1 + off:
+                f.write(f"f {a}//{a} {b}//{b} {c}//{c}\n")
+            off += len(v)
+
+
 def scene_to_json(scene, path):
     d = {"name": scene.name,
          "meshes": [{"pos": v["pos"].tolist(), "normal": v["normal"].tolist(), "uv": v["uv"].tolist(),
