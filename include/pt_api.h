@@ -188,7 +188,8 @@ enum {
   PT_OPT_SKY_MODE = 4,        /* 0 = ray-march on every miss (reference, SampleSky.hlsl:7-47); 1 = direction LUT (extension) */
   PT_OPT_EXTEND_FETCH_MIN = 5,     /* tuning: refill idle lanes of a wave once this many (1..64) are idle */
   PT_OPT_EXTEND_POSTPONE_PCT = 6,  /* tuning: postpone triangle tests while < this % of busy lanes have any (0 = never) */
-  PT_OPT_EXTEND_BLOCKS_PER_CU = 7  /* tuning: persistent grid = CUs x this (0 = occupancy query) */
+  PT_OPT_EXTEND_BLOCKS_PER_CU = 7, /* tuning: persistent grid = CUs x this (0 = occupancy query) */
+  PT_OPT_EXTEND_LDS_STACK = 8      /* tuning: per-lane traversal-stack entries kept in LDS (rest spills to HBM) */
 };
 
 /* ---- lifetime (replaces the RenderCore device + handle ownership, PathTracer.cpp:45-77,417-437) ---- */

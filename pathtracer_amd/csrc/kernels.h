@@ -15,7 +15,8 @@ struct DeviceScene {
   const float2* vertex_uv = nullptr;
   const uint32_t* instance_material = nullptr;
   const float4* materials = nullptr;   // emission.xyz, rgba8 bits
-  uint32_t stack_entries = 0;          // LDS stack entries per lane needed by trace_closest
+  uint32_t stack_entries = 0;          // stack entries per lane the traversal may need (2 per BVH level + 2)
+  uint2* spill = nullptr;              // global spill region of the per-lane stacks: [wave][entry][lane]
 };
 
 // device counter block (u32), zeroed at the start of every wavefront batch. Every counter sits on its own
@@ -54,6 +55,7 @@ struct LaunchCfg {
   uint32_t fetch_min = 16;    // extend: refill idle lanes once this many of the 64 are idle
   uint32_t postpone_pct = 35; // extend: postpone triangle tests while fewer than this % of busy lanes have any
   int extend_blocks_per_cu = 0; // 0 = from the occupancy query
+  uint32_t lds_stack_entries = 8; // per-lane stack entries kept in LDS; deeper entries spill to global memory
 };
 
 void launch_transmittance_lut(const PtAtmosphere& atm, uint2* lut, hipStream_t s);

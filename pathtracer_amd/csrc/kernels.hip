@@ -125,10 +125,14 @@ __global__ void __launch_bounds__(256) k_extend(const uint4* __restrict__ nodes,
                                                 const float4* __restrict__ ray_o, const float4* __restrict__ ray_d,
                                                 float4* __restrict__ hits, const uint32_t* __restrict__ count_ptr,
                                                 uint32_t* __restrict__ work_cursor, unsigned long long* __restrict__ stats,
-                                                uint32_t stack_entries, uint32_t stride, uint32_t fetch_min, uint32_t postpone_pct) {
+                                                uint32_t lds_entries, uint32_t spill_entries, uint2* __restrict__ spill, uint32_t stride, uint32_t fetch_min,
+                                                uint32_t postpone_pct) {
   extern __shared__ uint2 s_stack[];
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-  uint2* stk = s_stack + (size_t)wave * stack_entries * 64u + lane;
+  LaneStack stk;
+  stk.lds = s_stack + (size_t)wave * lds_entries * 64u + lane;
+  stk.spill = spill + ((size_t)blockIdx.x * (blockDim.x >> 6) + wave) * spill_entries * 64u + lane;
+  stk.lds_entries = (int)lds_entries;
   const uint32_t n = *count_ptr;
   // chunk: large enough to amortise the atomic, small enough to balance the tail (~8 chunks per wave)
   const uint32_t total_waves = gridDim.x * (blockDim.x >> 6);
@@ -193,7 +197,7 @@ __global__ void __launch_bounds__(256) k_extend(const uint4* __restrict__ nodes,
       const unsigned long long m = __ballot(has);
       if (m == 0ull) break;
       if ((uint32_t)__popcll(m) * 100u < n_busy * postpone_pct) {
-        if (has) { stk[tr.sp * 64] = tr.tg; ++tr.sp; tr.tg.y = 0u; }   // postpone: too few lanes have triangle work
+        if (has) { stk.put(tr.sp, tr.tg); ++tr.sp; tr.tg.y = 0u; }   // postpone: too few lanes have triangle work
         break;
       }
       if (has) {
@@ -209,7 +213,7 @@ __global__ void __launch_bounds__(256) k_extend(const uint4* __restrict__ nodes,
         busy = false;
       } else {
         --tr.sp;
-        tr.ng = stk[tr.sp * 64];
+        tr.ng = stk.get(tr.sp);
       }
     }
   }
@@ -475,7 +479,9 @@ int extend_occupancy_blocks(uint32_t stack_entries) {
 static size_t g_extend_lds_granted = 0;
 void launch_extend(const DeviceScene& sc, const float4* ray_o, const float4* ray_d, uint32_t stride, float4* hits, const uint32_t* count,
                    uint32_t* work_cursor, unsigned long long* stats, bool count_traversal, const LaunchCfg& cfg, hipStream_t s) {
-  const size_t lds = extend_lds_bytes(sc.stack_entries);
+  const uint32_t lds_entries = sc.stack_entries < cfg.lds_stack_entries ? sc.stack_entries : cfg.lds_stack_entries;
+  const uint32_t spill_entries = sc.stack_entries - lds_entries;
+  const size_t lds = extend_lds_bytes(lds_entries);
   if (lds > 64 * 1024 && lds > g_extend_lds_granted) {   // deep BVHs: opt in to more than the default dynamic-LDS limit
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_extend<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_extend<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -483,10 +489,10 @@ void launch_extend(const DeviceScene& sc, const float4* ray_o, const float4* ray
   }
   if (count_traversal)
     hipLaunchKernelGGL(k_extend<true>, dim3(cfg.extend_blocks), dim3(256), lds, s, sc.nodes, sc.tris, ray_o, ray_d, hits, count,
-                       work_cursor, stats, sc.stack_entries, stride, cfg.fetch_min, cfg.postpone_pct);
+                       work_cursor, stats, lds_entries, spill_entries, sc.spill, stride, cfg.fetch_min, cfg.postpone_pct);
   else
     hipLaunchKernelGGL(k_extend<false>, dim3(cfg.extend_blocks), dim3(256), lds, s, sc.nodes, sc.tris, ray_o, ray_d, hits, count,
-                       work_cursor, stats, sc.stack_entries, stride, cfg.fetch_min, cfg.postpone_pct);
+                       work_cursor, stats, lds_entries, spill_entries, sc.spill, stride, cfg.fetch_min, cfg.postpone_pct);
 }
 
 void launch_shade(const PtRtConsts& c, const DeviceScene& sc, const WavefrontBuffers& wb, int bounce, uint32_t w, uint32_t h,

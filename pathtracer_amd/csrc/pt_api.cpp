@@ -284,11 +284,17 @@ int pt_set_option(pt_ctx* ctx, int option, int64_t value) {
       if (value < 0 || value > 100) return ctx->fail(PT_ERR_INVALID_ARG, "postpone_pct must be 0..100");
       ctx->cfg.postpone_pct = (uint32_t)value;
       return PT_OK;
+    case PT_OPT_EXTEND_LDS_STACK:
+      if (value < 1 || value > 128) return ctx->fail(PT_ERR_INVALID_ARG, "LDS stack entries must be 1..128");
+      ctx->cfg.lds_stack_entries = (uint32_t)value;
+      if (ctx->has_scene)
+        ctx->cfg.extend_blocks = ctx->cfg.num_cus * (ctx->cfg.extend_blocks_per_cu > 0 ? ctx->cfg.extend_blocks_per_cu : std::max(1, std::min(8, extend_occupancy_blocks(std::min(ctx->ds.stack_entries, ctx->cfg.lds_stack_entries)))));
+      return PT_OK;
     case PT_OPT_EXTEND_BLOCKS_PER_CU:
       if (value < 0 || value > 16) return ctx->fail(PT_ERR_INVALID_ARG, "blocks per CU must be 0..16");
       ctx->cfg.extend_blocks_per_cu = (int)value;
       if (ctx->has_scene)
-        ctx->cfg.extend_blocks = ctx->cfg.num_cus * (value > 0 ? (int)value : std::max(1, std::min(8, extend_occupancy_blocks(ctx->ds.stack_entries))));
+        ctx->cfg.extend_blocks = ctx->cfg.num_cus * (value > 0 ? (int)value : std::max(1, std::min(8, extend_occupancy_blocks(std::min(ctx->ds.stack_entries, ctx->cfg.lds_stack_entries)))));
       return PT_OK;
     default: return ctx->fail(PT_ERR_INVALID_ARG, "unknown option");
   }
@@ -339,9 +345,16 @@ int pt_scene_create(pt_ctx* ctx, const PtMeshDesc* meshes, uint32_t num_meshes, 
   ctx->ds.instance_material = d_im;
   ctx->ds.materials = d_mat;
   ctx->ds.stack_entries = 2 * bvh.max_depth + 2;   // <=1 sibling group + <=1 postponed triangle group per level
-  if (extend_lds_bytes(ctx->ds.stack_entries) > 160 * 1024)
-    return ctx->fail(PT_ERR_UNSUPPORTED, "BVH deeper than the LDS traversal stack supports (" + std::to_string(bvh.max_depth) + " levels)");
-  ctx->cfg.extend_blocks = ctx->cfg.num_cus * (ctx->cfg.extend_blocks_per_cu > 0 ? ctx->cfg.extend_blocks_per_cu : std::max(1, std::min(8, extend_occupancy_blocks(ctx->ds.stack_entries))));
+  if (bvh.max_depth > 62)
+    return ctx->fail(PT_ERR_UNSUPPORTED, "BVH deeper than the traversal stack supports (" + std::to_string(bvh.max_depth) + " levels)");
+  {
+    // spill region sized for the largest persistent grid we ever launch (16 blocks per CU x 4 waves)
+    const size_t waves = (size_t)ctx->cfg.num_cus * 16u * 4u;
+    uint2* d_spill = nullptr;
+    if ((rc = dev_alloc(ctx, &d_spill, waves * ctx->ds.stack_entries * 64u, &ctx->scene_allocs))) return rc;
+    ctx->ds.spill = d_spill;
+  }
+  ctx->cfg.extend_blocks = ctx->cfg.num_cus * (ctx->cfg.extend_blocks_per_cu > 0 ? ctx->cfg.extend_blocks_per_cu : std::max(1, std::min(8, extend_occupancy_blocks(std::min(ctx->ds.stack_entries, ctx->cfg.lds_stack_entries)))));
 
   PtSceneInfo& in = ctx->info;
   in.num_triangles = fs.num_triangles();

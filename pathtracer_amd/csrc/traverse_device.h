@@ -80,6 +80,23 @@ struct TriTester {
 
 __device__ __forceinline__ float safe_dir(float d) { return fabsf(d) < 1e-25f ? copysignf(1e-25f, d) : d; }
 
+// Per-lane stack of 8-byte entries: the first `lds_entries` live in LDS ([entry][lane]: lane-contiguous, conflict-free
+// ds_read/write_b64), deeper entries spill to a per-wave global region with the same layout. Typical traversals stay
+// within the LDS part; the spill only bounds the worst case (2 entries per BVH level).
+struct LaneStack {
+  uint2* lds;        // this lane's slot of LDS entry 0
+  uint2* spill;      // this lane's slot of spill entry 0
+  int lds_entries;
+  __device__ __forceinline__ void put(int sp, uint2 v) const {
+    if (sp < lds_entries) lds[sp * 64] = v;
+    else spill[(sp - lds_entries) * 64] = v;
+  }
+  __device__ __forceinline__ uint2 get(int sp) const {
+    if (sp < lds_entries) return lds[sp * 64];
+    return spill[(sp - lds_entries) * 64];
+  }
+};
+
 // Per-lane traversal state of one ray. The wave-level loop that drives it (replenishing finished lanes, postponing
 // sparse triangle work) lives in k_extend; this struct holds what one lane carries between loop iterations.
 struct Traverser {
@@ -107,12 +124,12 @@ struct Traverser {
   __device__ __forceinline__ bool has_node_work() const { return ng.y > 0x00FFFFFFu; }
 
   // Pops the nearest pending internal child, fetches its 80-byte node (5 x 128-bit loads) and intersects the 8
-  // quantised child boxes. `stk` = this lane's slot of stack entry 0; entries are 64 slots apart.
-  __device__ __forceinline__ void node_step(const uint4* __restrict__ nodes, uint2* stk) {
+  // quantised child boxes.
+  __device__ __forceinline__ void node_step(const uint4* __restrict__ nodes, const LaneStack& stk) {
     const uint32_t hits = ng.y;
     const int b = 31 - __clz((int)hits);
     ng.y &= ~(1u << b);
-    if (ng.y > 0x00FFFFFFu) { stk[sp * 64] = ng; ++sp; }
+    if (ng.y > 0x00FFFFFFu) { stk.put(sp, ng); ++sp; }
     const uint32_t slot = ((uint32_t)b - 24u) ^ oct;
     const uint32_t rel = __popc(hits & ~(0xFFFFFFFFu << slot));
     const uint4* np = nodes + (size_t)(ng.x + rel) * 5;
