@@ -43,8 +43,8 @@ def make_workload(name):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=6)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--spp-per-step", type=int, default=4)
@@ -52,6 +52,8 @@ def main():
     ap.add_argument("--workload", default="atrium", choices=["atrium", "street", "courtyard", "cornell"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
+    ap.add_argument("--all-ranks-on-gpu0", action="store_true", help="rehearsal: every rank uses cuda:0")
     args = ap.parse_args()
 
     import numpy as np
@@ -63,9 +65,14 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.all_ranks_on_gpu0:
+        local_rank = 0
     if world > 1:
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=args.backend)
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
@@ -113,6 +120,10 @@ def main():
 
     for i in range(WU):
         step(i)
+    if world > 1:   # warm the collective path too (communicator/channel set-up is lazy), on a scratch tensor
+        scratch = torch.zeros_like(target)
+        dist.reduce(scratch, dst=0, op=dist.ReduceOp.SUM)
+        del scratch
     barrier()
     ctx.stats_reset()
     barrier()

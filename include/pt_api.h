@@ -251,6 +251,9 @@ int pt_trace_rays(pt_ctx* ctx, const PtRay* rays, uint64_t num_rays, PtHit* hits
 int pt_trace_rays_device(pt_ctx* ctx, const PtRay* device_rays, uint64_t num_rays, PtHit* device_hits);
 /* Evaluate one shading/sky device function on n rows of host inputs (see PT_FN_* for row layouts). */
 int pt_debug_eval(pt_ctx* ctx, int fn, const PtRtConsts* consts, const float* in, uint64_t n, float* out);
+/* Copy out the ray queue that the LAST wavefront batch built for `bounce` (valid until the next render call; the
+   queue of bounce b is overwritten by bounce b+2 of the same batch). host_rays may be NULL to query the count. */
+int pt_debug_read_queue(pt_ctx* ctx, uint32_t bounce, PtRay* host_rays, uint64_t capacity, uint64_t* count_out);
 int pt_stats_get(pt_ctx* ctx, PtStats* out);   /* synchronises the stream first */
 int pt_stats_reset(pt_ctx* ctx);
 

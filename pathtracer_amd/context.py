@@ -160,6 +160,13 @@ class Context:
         self._ck(self.lib.pt_debug_eval(self.h, fn, cp, api.ptr(rows), len(rows), api.ptr(out)))
         return out
 
+    def debug_read_queue(self, bounce):
+        n = C.c_uint64()
+        self._ck(self.lib.pt_debug_read_queue(self.h, bounce, None, 0, C.byref(n)))
+        out = np.empty(n.value, dtype=api.RAY_DTYPE)
+        self._ck(self.lib.pt_debug_read_queue(self.h, bounce, api.ptr(out), n.value, C.byref(n)))
+        return out
+
     # ---- misc ----
     def set_option(self, opt, value):
         self._ck(self.lib.pt_set_option(self.h, opt, int(value)))

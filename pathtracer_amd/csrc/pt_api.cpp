@@ -593,6 +593,29 @@ int pt_debug_eval(pt_ctx* ctx, int fn, const PtRtConsts* consts, const float* in
   return PT_OK;
 }
 
+int pt_debug_read_queue(pt_ctx* ctx, uint32_t bounce, PtRay* host_rays, uint64_t capacity, uint64_t* count_out) {
+  PT_REQUIRE_CTX();
+  if (!ctx->wb.counters || !count_out || bounce > 62) return ctx->fail(PT_ERR_INVALID_ARG, "no wavefront state or bad arguments");
+  PT_HIP(hipStreamSynchronize(ctx->stream));
+  uint32_t n = 0;
+  PT_HIP(hipMemcpy(&n, ctx->wb.counters + CTR_AT(CTR_QCOUNT0 + bounce), sizeof(n), hipMemcpyDeviceToHost));
+  *count_out = n;
+  if (!host_rays) return PT_OK;
+  if (capacity < n) return ctx->fail(PT_ERR_INVALID_ARG, "host array too small");
+  std::vector<float4> o(n), d(n);
+  const int buf = (int)(bounce & 1u);
+  if (n) {
+    PT_HIP(hipMemcpy(o.data(), ctx->wb.ray_o[buf], (size_t)n * sizeof(float4), hipMemcpyDeviceToHost));
+    PT_HIP(hipMemcpy(d.data(), ctx->wb.ray_d[buf], (size_t)n * sizeof(float4), hipMemcpyDeviceToHost));
+  }
+  for (uint32_t i = 0; i < n; ++i) {
+    PtRay& r = host_rays[i];
+    r.origin[0] = o[i].x; r.origin[1] = o[i].y; r.origin[2] = o[i].z; r.tmin = o[i].w;
+    r.dir[0] = d[i].x; r.dir[1] = d[i].y; r.dir[2] = d[i].z; r.tmax = d[i].w;
+  }
+  return PT_OK;
+}
+
 int pt_stats_get(pt_ctx* ctx, PtStats* out) {
   PT_REQUIRE_CTX();
   if (!out) return ctx->fail(PT_ERR_INVALID_ARG, "output pointer is null");

@@ -25,7 +25,7 @@ def reduce_sum_to_root(accum, num_samples, group=None, root=0):
     cnt = torch.tensor([int(num_samples)], dtype=torch.int64, device=accum.device)
     dist.reduce(accum, dst=root, op=dist.ReduceOp.SUM, group=group)
     dist.all_reduce(cnt, op=dist.ReduceOp.SUM, group=group)
-    return accum, int(cnt.item())
+    return accum, int(cnt.item())   # on non-root ranks `accum` is unspecified after the reduce
 
 
 def gather_ordered_sum_to_root(accum, num_samples, group=None, root=0):
