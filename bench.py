@@ -25,6 +25,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 NODE_BYTES, TRI_BYTES, RAY_IO_BYTES = 80, 48, 48   # B_ray = 80*N_node + 48*N_tri + 48
+DEF_DEFER, DEF_POSTPONE = 4, 50                   # the library defaults (csrc/kernels.h LaunchCfg)
 
 
 def make_workload(name):
@@ -146,14 +147,23 @@ def main():
 
     roofline = None
     if rank == 0 and not args.no_roofline:
-        # (1) algorithmic bytes: counting instantiation of the extend kernel on one step of the same workload
-        ctx.stats_reset()
-        ctx.set_option(api.PT_OPT_COUNT_TRAVERSAL, 1)
-        step(total_steps)
-        sc_ = ctx.stats()
-        ctx.set_option(api.PT_OPT_COUNT_TRAVERSAL, 0)
+        # (1) algorithmic bytes: counting instantiation of the extend kernel on one step of the same workload, run with
+        #     the CANONICAL schedule (nearest-first, every triangle group tested at once: no postponing / deferral), so
+        #     the figure does not grow when a faster schedule visits a few more nodes. The shipped schedule's own
+        #     counts are reported beside it.
+        def count_pass(defer, postpone):
+            ctx.set_option(api.PT_OPT_EXTEND_DEFER, defer)
+            ctx.set_option(api.PT_OPT_EXTEND_POSTPONE_PCT, postpone)
+            ctx.stats_reset()
+            ctx.set_option(api.PT_OPT_COUNT_TRAVERSAL, 1)
+            step(total_steps)
+            r = ctx.stats()
+            ctx.set_option(api.PT_OPT_COUNT_TRAVERSAL, 0)
+            return r
+        sc_ = count_pass(0, 0)
         nodes_per_ray = sc_.nodes_visited / max(1, sc_.rays)
         tris_per_ray = sc_.tris_tested / max(1, sc_.rays)
+        ship = count_pass(DEF_DEFER, DEF_POSTPONE)
         bytes_per_ray = NODE_BYTES * nodes_per_ray + TRI_BYTES * tris_per_ray + RAY_IO_BYTES
         # (2) extend-kernel time: HIP events on the ctx stream around every extend launch, K more steps
         ctx.stats_reset()
@@ -168,6 +178,10 @@ def main():
             "bound": "hbm", "kernel": "k_extend", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
             "nodes_per_ray": round(nodes_per_ray, 3), "tris_per_ray": round(tris_per_ray, 3),
+            "shipped_schedule": {"nodes_per_ray": round(ship.nodes_visited / max(1, ship.rays), 3),
+                                 "tris_per_ray": round(ship.tris_tested / max(1, ship.rays), 3),
+                                 "node_phase_lane_util": round(ship.nodes_visited / max(1, 64 * ship.node_wave_steps), 3),
+                                 "tri_phase_lane_util": round(ship.tris_tested / max(1, 64 * ship.tri_wave_steps), 3)},
             "bytes_per_ray": round(bytes_per_ray, 1),
             "launches": int(se.extend_launches), "avg_launch_ms": round(se.extend_ms / max(1, se.extend_launches), 4),
             "bytes_per_launch": round(bytes_per_ray * se.rays / max(1, se.extend_launches), 1),

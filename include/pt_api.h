@@ -165,6 +165,8 @@ typedef struct PtStats {
   double render_ms;        /* sum of whole pt_render durations, HIP events (only when timing is on) */
   uint64_t rays_bounce[16];      /* rays traced at bounce b (b >= 15 folded into [15]) */
   double extend_ms_bounce[16];   /* extend-kernel time at bounce b (only when timing is on) */
+  uint64_t node_wave_steps;      /* wave-level node steps (counting on): nodes_visited / (64*this) = lane utilisation */
+  uint64_t tri_wave_steps;       /* wave-level triangle steps (counting on) */
 } PtStats;
 
 typedef struct PtSceneInfo {
@@ -189,7 +191,8 @@ enum {
   PT_OPT_EXTEND_FETCH_MIN = 5,     /* tuning: refill idle lanes of a wave once this many (1..64) are idle */
   PT_OPT_EXTEND_POSTPONE_PCT = 6,  /* tuning: postpone triangle tests while < this % of busy lanes have any (0 = never) */
   PT_OPT_EXTEND_BLOCKS_PER_CU = 7, /* tuning: persistent grid = CUs x this (0 = occupancy query) */
-  PT_OPT_EXTEND_LDS_STACK = 8      /* tuning: per-lane traversal-stack entries kept in LDS (rest spills to HBM) */
+  PT_OPT_EXTEND_LDS_STACK = 8,     /* tuning: per-lane traversal-stack entries kept in LDS (rest spills to HBM) */
+  PT_OPT_EXTEND_DEFER = 9          /* tuning: 0 = postpone triangles on the stack; N>0 = park up to N groups per lane */
 };
 
 /* ---- lifetime (replaces the RenderCore device + handle ownership, PathTracer.cpp:45-77,417-437) ---- */

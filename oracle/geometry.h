@@ -140,9 +140,13 @@ static inline bool intersect_tri(const RayPre& r, const Tri& tri, uint32_t prim,
   return false;
 }
 
+// A ray with a NaN/Inf origin or direction hits nothing (all comparisons of the triangle test fail): defined as a miss.
+static inline bool ray_is_finite(float3 org, float3 dir) { return std::isfinite((org.x + org.y + org.z) + (dir.x + dir.y + dir.z)); }
+
 static inline PtHit trace_brute(const Scene& S, float3 org, float tmin, float3 dir, float tmax) {
   RayPre r = ray_precompute(org, dir);
   PtHit best; best.t = tmax; best.u = 0; best.v = 0; best.prim = PT_MISS;
+  if (!ray_is_finite(org, dir)) { best.t = -1.0f; return best; }
   for (uint32_t i = 0; i < (uint32_t)S.tris.size(); ++i) intersect_tri(r, S.tris[i], i, tmin, best);
   if (best.prim == PT_MISS) best.t = -1.0f;
   return best;
@@ -265,7 +269,7 @@ struct TraceCounters { uint64_t nodes = 0, tris = 0; };
 static inline PtHit trace_bvh(const Scene& S, float3 org, float tmin, float3 dir, float tmax, TraceCounters* cnt = nullptr) {
   RayPre r = ray_precompute(org, dir);
   PtHit best; best.t = tmax; best.u = 0; best.v = 0; best.prim = PT_MISS;
-  if (S.tris.empty()) { best.t = -1.0f; return best; }
+  if (S.tris.empty() || !ray_is_finite(org, dir)) { best.t = -1.0f; return best; }
   const float o[3] = {org.x, org.y, org.z}, d[3] = {dir.x, dir.y, dir.z};
   const float id[3] = {1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z};
   uint32_t stack[128]; int sp = 0;

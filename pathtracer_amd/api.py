@@ -35,6 +35,7 @@ PT_OPT_EXTEND_FETCH_MIN = 5
 PT_OPT_EXTEND_POSTPONE_PCT = 6
 PT_OPT_EXTEND_BLOCKS_PER_CU = 7
 PT_OPT_EXTEND_LDS_STACK = 8
+PT_OPT_EXTEND_DEFER = 9
 
 (PT_FN_RAND01, PT_FN_FRESNEL, PT_FN_SPEC_PROB, PT_FN_SAMPLE_PHONG, PT_FN_EVAL_PHONG, PT_FN_COS_HEMISPHERE,
  PT_FN_LAMBERT, PT_FN_SKY, PT_FN_PRIMARY_RAY) = range(9)
@@ -104,7 +105,8 @@ class PtStats(C.Structure):
     _fields_ = [("samples", C.c_uint64), ("rays", C.c_uint64), ("shaded_hits", C.c_uint64), ("sky_misses", C.c_uint64),
                 ("nodes_visited", C.c_uint64), ("tris_tested", C.c_uint64), ("extend_launches", C.c_uint64),
                 ("extend_ms", C.c_double), ("render_ms", C.c_double),
-                ("rays_bounce", C.c_uint64 * 16), ("extend_ms_bounce", C.c_double * 16)]
+                ("rays_bounce", C.c_uint64 * 16), ("extend_ms_bounce", C.c_double * 16),
+                ("node_wave_steps", C.c_uint64), ("tri_wave_steps", C.c_uint64)]
 
 
 class PtSceneInfo(C.Structure):

@@ -32,7 +32,7 @@ enum {
   CTR_WORDS = 132 * 64
 };
 // persistent device statistics (u64)
-enum { ST_SAMPLES = 0, ST_RAYS, ST_SHADED, ST_SKY, ST_NODES, ST_TRIS, ST_RAYS_BOUNCE0 = 8, ST_WORDS = 8 + 64 };
+enum { ST_SAMPLES = 0, ST_RAYS, ST_SHADED, ST_SKY, ST_NODES, ST_TRIS, ST_NODE_WAVE_STEPS, ST_TRI_WAVE_STEPS, ST_RAYS_BOUNCE0 = 8, ST_WORDS = 8 + 64 };
 
 struct WavefrontBuffers {
   float4* ray_o[2] = {nullptr, nullptr};  // origin.xyz, tmin
@@ -53,9 +53,10 @@ struct LaunchCfg {
   int extend_blocks = 1024;   // persistent grid of the extend kernel
   int stream_blocks = 2048;   // grid cap of the grid-stride kernels
   uint32_t fetch_min = 16;    // extend: refill idle lanes once this many of the 64 are idle
-  uint32_t postpone_pct = 35; // extend: postpone triangle tests while fewer than this % of busy lanes have any
+  uint32_t postpone_pct = 50; // extend: postpone triangle tests while fewer than this % of busy lanes have any
   int extend_blocks_per_cu = 0; // 0 = from the occupancy query
   uint32_t lds_stack_entries = 8; // per-lane stack entries kept in LDS; deeper entries spill to global memory
+  uint32_t defer_entries = 4;     // >0: deferred-triangle schedule with this many parked groups per lane
 };
 
 void launch_transmittance_lut(const PtAtmosphere& atm, uint2* lut, hipStream_t s);
@@ -71,6 +72,6 @@ void launch_resolve(const WavefrontBuffers& wb, float4* accum, uint32_t w, uint3
 void launch_set_count(uint32_t* counter, uint32_t value, hipStream_t s);
 void launch_debug_eval(int fn, const PtRtConsts& c, const uint2* lut, const float* in, uint64_t n, float* out, hipStream_t s);
 size_t extend_lds_bytes(uint32_t stack_entries);
-int extend_occupancy_blocks(uint32_t stack_entries);
+int extend_occupancy_blocks(uint32_t lds_entries_total);
 
 }  // namespace pt

@@ -120,19 +120,22 @@ __global__ void __launch_bounds__(256) k_generate(PtRtConsts c, float4* __restri
 // lanes have any, so
 // that the wave spends its instructions on box tests or on triangle tests with most lanes active.
 
-template <bool COUNT>
+template <bool COUNT, bool DEFER>
 __global__ void __launch_bounds__(256) k_extend(const uint4* __restrict__ nodes, const uint4* __restrict__ tris,
                                                 const float4* __restrict__ ray_o, const float4* __restrict__ ray_d,
                                                 float4* __restrict__ hits, const uint32_t* __restrict__ count_ptr,
                                                 uint32_t* __restrict__ work_cursor, unsigned long long* __restrict__ stats,
                                                 uint32_t lds_entries, uint32_t spill_entries, uint2* __restrict__ spill, uint32_t stride, uint32_t fetch_min,
-                                                uint32_t postpone_pct) {
+                                                uint32_t postpone_pct, uint32_t dq_entries) {
   extern __shared__ uint2 s_stack[];
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   LaneStack stk;
   stk.lds = s_stack + (size_t)wave * lds_entries * 64u + lane;
   stk.spill = spill + ((size_t)blockIdx.x * (blockDim.x >> 6) + wave) * spill_entries * 64u + lane;
   stk.lds_entries = (int)lds_entries;
+  // DEFER: per-lane queue of deferred triangle groups, in LDS behind the stacks of the block's waves
+  uint2* dq = s_stack + (size_t)(blockDim.x >> 6) * lds_entries * 64u + (size_t)wave * dq_entries * 64u + lane;
+  uint32_t dqn = 0u;
   const uint32_t n = *count_ptr;
   // chunk: large enough to amortise the atomic, small enough to balance the tail (~8 chunks per wave)
   const uint32_t total_waves = gridDim.x * (blockDim.x >> 6);
@@ -144,7 +147,7 @@ __global__ void __launch_bounds__(256) k_extend(const uint4* __restrict__ nodes,
   bool busy = false;
   uint32_t ray_i = 0u;
   Traverser tr;
-  uint32_t n_nodes = 0u, n_tris = 0u;
+  uint32_t n_nodes = 0u, n_tris = 0u, n_node_steps = 0u, n_tri_steps = 0u;   // *_steps: wave-level, lane 0 only
 
   for (;;) {
     // ---- refill idle lanes from the wave's pool ----
@@ -173,8 +176,15 @@ __global__ void __launch_bounds__(256) k_extend(const uint4* __restrict__ nodes,
           TraceRay r;
           r.ox = ro.x; r.oy = ro.y; r.oz = ro.z; r.tmin = ro.w;
           r.dx = rd.x; r.dy = rd.y; r.dz = rd.z; r.tmax = rd.w;
-          tr.init(r);
-          busy = true;
+          // A ray with a NaN/Inf component can hit nothing (every comparison of the triangle test fails), but fmin/fmax
+          // drop NaNs, so its box tests would all pass and it would walk the whole BVH: report the miss right away.
+          const float chk = (r.ox + r.oy + r.oz) + (r.dx + r.dy + r.dz);
+          if (isfinite(chk)) {
+            tr.init(r);
+            busy = true;
+          } else {
+            hits[ray_i] = make_float4(-1.0f, 0.0f, 0.0f, __uint_as_float(0xFFFFFFFFu));
+          }
         }
         pool_next += take;
       }
@@ -183,43 +193,91 @@ __global__ void __launch_bounds__(256) k_extend(const uint4* __restrict__ nodes,
 
     // ---- one traversal iteration for the busy lanes ----
     const uint32_t n_busy = (uint32_t)__popcll(__ballot(busy));
-    if (busy) {
-      if (tr.has_node_work()) {
+    if (COUNT && __ballot(busy && tr.has_node_work()) != 0ull) ++n_node_steps;
+    if (!DEFER) {
+      if (busy) {
+        if (tr.has_node_work()) {
+          tr.node_step(nodes, stk);
+          if (COUNT) ++n_nodes;
+        } else {
+          tr.tg = tr.ng;
+          tr.ng = make_uint2(0u, 0u);
+        }
+      }
+      for (;;) {
+        const bool has = busy && tr.tg.y != 0u;
+        const unsigned long long m = __ballot(has);
+        if (m == 0ull) break;
+        if ((uint32_t)__popcll(m) * 100u < n_busy * postpone_pct) {
+          if (has) { stk.put(tr.sp, tr.tg); ++tr.sp; tr.tg.y = 0u; }   // postpone: too few lanes have triangle work
+          break;
+        }
+        if (COUNT) ++n_tri_steps;
+        if (has) {
+          tr.tri_step(tris);
+          if (COUNT) ++n_tris;
+        }
+      }
+      if (busy && !tr.has_node_work()) {
+        if (tr.sp == 0) {
+          HitRec hr = tr.best;
+          if (hr.prim == 0xFFFFFFFFu) hr.t = -1.0f;
+          hits[ray_i] = make_float4(hr.t, hr.u, hr.v, __uint_as_float(hr.prim));
+          busy = false;
+        } else {
+          --tr.sp;
+          tr.ng = stk.get(tr.sp);
+        }
+      }
+    } else {
+      // Deferred-triangle schedule: triangle groups never go on the traversal stack. A lane parks them in its small
+      // queue and keeps doing box tests; the wave runs a triangle phase only when enough lanes have parked work
+      // (or a queue is full), so both phases run with most lanes active.
+      if (busy && tr.has_node_work()) {
         tr.node_step(nodes, stk);
         if (COUNT) ++n_nodes;
-      } else {
-        tr.tg = tr.ng;
-        tr.ng = make_uint2(0u, 0u);
       }
-    }
-    for (;;) {
-      const bool has = busy && tr.tg.y != 0u;
-      const unsigned long long m = __ballot(has);
-      if (m == 0ull) break;
-      if ((uint32_t)__popcll(m) * 100u < n_busy * postpone_pct) {
-        if (has) { stk.put(tr.sp, tr.tg); ++tr.sp; tr.tg.y = 0u; }   // postpone: too few lanes have triangle work
-        break;
+      const bool pending = busy && (tr.tg.y != 0u || dqn != 0u);
+      const unsigned long long pm = __ballot(pending);
+      if (pm != 0ull) {
+        const unsigned long long full = __ballot(busy && tr.tg.y != 0u && dqn == dq_entries);
+        if (full != 0ull || (uint32_t)__popcll(pm) * 100u >= n_busy * postpone_pct) {
+          for (;;) {
+            if (busy && tr.tg.y == 0u && dqn != 0u) { --dqn; tr.tg = dq[dqn * 64u]; }
+            const bool has = busy && tr.tg.y != 0u;
+            const unsigned long long m = __ballot(has);
+            if (m == 0ull) break;
+            const unsigned long long must = __ballot(has && dqn == dq_entries);
+            if (must == 0ull && (uint32_t)__popcll(m) * 200u < n_busy * postpone_pct) break;   // tail: leave the rest parked
+            if (COUNT) ++n_tri_steps;
+            if (has) {
+              tr.tri_step(tris);
+              if (COUNT) ++n_tris;
+            }
+          }
+        }
+        if (busy && tr.tg.y != 0u) { dq[dqn * 64u] = tr.tg; ++dqn; tr.tg.y = 0u; }   // park what is left (room is guaranteed)
       }
-      if (has) {
-        tr.tri_step(tris);
-        if (COUNT) ++n_tris;
-      }
-    }
-    if (busy && !tr.has_node_work()) {
-      if (tr.sp == 0) {
-        HitRec hr = tr.best;
-        if (hr.prim == 0xFFFFFFFFu) hr.t = -1.0f;
-        hits[ray_i] = make_float4(hr.t, hr.u, hr.v, __uint_as_float(hr.prim));
-        busy = false;
-      } else {
-        --tr.sp;
-        tr.ng = stk.get(tr.sp);
+      if (busy && !tr.has_node_work()) {
+        if (tr.sp != 0) {
+          --tr.sp;
+          tr.ng = stk.get(tr.sp);
+        } else if (dqn == 0u) {
+          HitRec hr = tr.best;
+          if (hr.prim == 0xFFFFFFFFu) hr.t = -1.0f;
+          hits[ray_i] = make_float4(hr.t, hr.u, hr.v, __uint_as_float(hr.prim));
+          busy = false;
+        }   // else: only parked triangles left — wait for the wave's next triangle phase
       }
     }
   }
   if (COUNT) {
     atomicAdd(&stats[ST_NODES], (unsigned long long)n_nodes);
     atomicAdd(&stats[ST_TRIS], (unsigned long long)n_tris);
+    if (lane == 0u) {
+      atomicAdd(&stats[ST_NODE_WAVE_STEPS], (unsigned long long)n_node_steps);
+      atomicAdd(&stats[ST_TRI_WAVE_STEPS], (unsigned long long)n_tri_steps);
+    }
   }
 }
 
@@ -468,11 +526,11 @@ void launch_generate(const PtRtConsts& c, const WavefrontBuffers& wb, uint32_t w
                      wb.counters, w, h, first_sample, n);
 }
 
-size_t extend_lds_bytes(uint32_t stack_entries) { return (size_t)stack_entries * 64u * sizeof(uint2) * 4u; }
+size_t extend_lds_bytes(uint32_t lds_entries_total) { return (size_t)lds_entries_total * 64u * sizeof(uint2) * 4u; }
 
 int extend_occupancy_blocks(uint32_t stack_entries) {
   int nb = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_extend<false>, 256, extend_lds_bytes(stack_entries)) != hipSuccess || nb < 1) nb = 1;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_extend<false, false>, 256, extend_lds_bytes(stack_entries)) != hipSuccess || nb < 1) nb = 1;
   return nb;
 }
 
@@ -481,18 +539,24 @@ void launch_extend(const DeviceScene& sc, const float4* ray_o, const float4* ray
                    uint32_t* work_cursor, unsigned long long* stats, bool count_traversal, const LaunchCfg& cfg, hipStream_t s) {
   const uint32_t lds_entries = sc.stack_entries < cfg.lds_stack_entries ? sc.stack_entries : cfg.lds_stack_entries;
   const uint32_t spill_entries = sc.stack_entries - lds_entries;
-  const size_t lds = extend_lds_bytes(lds_entries);
+  const uint32_t dq = cfg.defer_entries;
+  const size_t lds = extend_lds_bytes(lds_entries + dq);
   if (lds > 64 * 1024 && lds > g_extend_lds_granted) {   // deep BVHs: opt in to more than the default dynamic-LDS limit
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_extend<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_extend<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_extend<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_extend<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_extend<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_extend<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     g_extend_lds_granted = lds;
   }
-  if (count_traversal)
-    hipLaunchKernelGGL(k_extend<true>, dim3(cfg.extend_blocks), dim3(256), lds, s, sc.nodes, sc.tris, ray_o, ray_d, hits, count,
-                       work_cursor, stats, lds_entries, spill_entries, sc.spill, stride, cfg.fetch_min, cfg.postpone_pct);
-  else
-    hipLaunchKernelGGL(k_extend<false>, dim3(cfg.extend_blocks), dim3(256), lds, s, sc.nodes, sc.tris, ray_o, ray_d, hits, count,
-                       work_cursor, stats, lds_entries, spill_entries, sc.spill, stride, cfg.fetch_min, cfg.postpone_pct);
+#define PT_LAUNCH_EXTEND(C, D)                                                                                              \
+  hipLaunchKernelGGL((k_extend<C, D>), dim3(cfg.extend_blocks), dim3(256), lds, s, sc.nodes, sc.tris, ray_o, ray_d, hits, count, \
+                     work_cursor, stats, lds_entries, spill_entries, sc.spill, stride, cfg.fetch_min, cfg.postpone_pct, dq)
+  if (dq > 0) {
+    if (count_traversal) PT_LAUNCH_EXTEND(true, true); else PT_LAUNCH_EXTEND(false, true);
+  } else {
+    if (count_traversal) PT_LAUNCH_EXTEND(true, false); else PT_LAUNCH_EXTEND(false, false);
+  }
+#undef PT_LAUNCH_EXTEND
 }
 
 void launch_shade(const PtRtConsts& c, const DeviceScene& sc, const WavefrontBuffers& wb, int bounce, uint32_t w, uint32_t h,

@@ -288,13 +288,19 @@ int pt_set_option(pt_ctx* ctx, int option, int64_t value) {
       if (value < 1 || value > 128) return ctx->fail(PT_ERR_INVALID_ARG, "LDS stack entries must be 1..128");
       ctx->cfg.lds_stack_entries = (uint32_t)value;
       if (ctx->has_scene)
-        ctx->cfg.extend_blocks = ctx->cfg.num_cus * (ctx->cfg.extend_blocks_per_cu > 0 ? ctx->cfg.extend_blocks_per_cu : std::max(1, std::min(8, extend_occupancy_blocks(std::min(ctx->ds.stack_entries, ctx->cfg.lds_stack_entries)))));
+        ctx->cfg.extend_blocks = ctx->cfg.num_cus * (ctx->cfg.extend_blocks_per_cu > 0 ? ctx->cfg.extend_blocks_per_cu : std::max(1, std::min(8, extend_occupancy_blocks(std::min(ctx->ds.stack_entries, ctx->cfg.lds_stack_entries) + ctx->cfg.defer_entries))));
+      return PT_OK;
+    case PT_OPT_EXTEND_DEFER:
+      if (value < 0 || value > 16) return ctx->fail(PT_ERR_INVALID_ARG, "deferred-triangle queue must be 0..16 entries");
+      ctx->cfg.defer_entries = (uint32_t)value;
+      if (ctx->has_scene)
+        ctx->cfg.extend_blocks = ctx->cfg.num_cus * (ctx->cfg.extend_blocks_per_cu > 0 ? ctx->cfg.extend_blocks_per_cu : std::max(1, std::min(8, extend_occupancy_blocks(std::min(ctx->ds.stack_entries, ctx->cfg.lds_stack_entries) + ctx->cfg.defer_entries))));
       return PT_OK;
     case PT_OPT_EXTEND_BLOCKS_PER_CU:
       if (value < 0 || value > 16) return ctx->fail(PT_ERR_INVALID_ARG, "blocks per CU must be 0..16");
       ctx->cfg.extend_blocks_per_cu = (int)value;
       if (ctx->has_scene)
-        ctx->cfg.extend_blocks = ctx->cfg.num_cus * (value > 0 ? (int)value : std::max(1, std::min(8, extend_occupancy_blocks(std::min(ctx->ds.stack_entries, ctx->cfg.lds_stack_entries)))));
+        ctx->cfg.extend_blocks = ctx->cfg.num_cus * (value > 0 ? (int)value : std::max(1, std::min(8, extend_occupancy_blocks(std::min(ctx->ds.stack_entries, ctx->cfg.lds_stack_entries) + ctx->cfg.defer_entries))));
       return PT_OK;
     default: return ctx->fail(PT_ERR_INVALID_ARG, "unknown option");
   }
@@ -354,7 +360,7 @@ int pt_scene_create(pt_ctx* ctx, const PtMeshDesc* meshes, uint32_t num_meshes, 
     if ((rc = dev_alloc(ctx, &d_spill, waves * ctx->ds.stack_entries * 64u, &ctx->scene_allocs))) return rc;
     ctx->ds.spill = d_spill;
   }
-  ctx->cfg.extend_blocks = ctx->cfg.num_cus * (ctx->cfg.extend_blocks_per_cu > 0 ? ctx->cfg.extend_blocks_per_cu : std::max(1, std::min(8, extend_occupancy_blocks(std::min(ctx->ds.stack_entries, ctx->cfg.lds_stack_entries)))));
+  ctx->cfg.extend_blocks = ctx->cfg.num_cus * (ctx->cfg.extend_blocks_per_cu > 0 ? ctx->cfg.extend_blocks_per_cu : std::max(1, std::min(8, extend_occupancy_blocks(std::min(ctx->ds.stack_entries, ctx->cfg.lds_stack_entries) + ctx->cfg.defer_entries))));
 
   PtSceneInfo& in = ctx->info;
   in.num_triangles = fs.num_triangles();
@@ -631,6 +637,8 @@ int pt_stats_get(pt_ctx* ctx, PtStats* out) {
     out->sky_misses = h[ST_SKY];
     out->nodes_visited = h[ST_NODES];
     out->tris_tested = h[ST_TRIS];
+    out->node_wave_steps = h[ST_NODE_WAVE_STEPS];
+    out->tri_wave_steps = h[ST_TRI_WAVE_STEPS];
     for (int b = 0; b < 64; ++b) out->rays_bounce[std::min(15, b)] += h[ST_RAYS_BOUNCE0 + b];
   }
   for (int b = 0; b < 16; ++b) out->extend_ms_bounce[b] = ctx->extend_ms_bounce[b];

@@ -52,7 +52,10 @@ struct TriTester {
     float U = Cx * By - Cy * Bx;
     float V = Ax * Cy - Ay * Cx;
     float W = Bx * Ay - By * Ax;
-    if (U == 0.0f || V == 0.0f || W == 0.0f) {
+    // fp64 fallback only when an edge function is exactly zero. The wave-level test keeps it a real (rarely taken)
+    // branch: without it the compiler if-converts the fp64 arithmetic into every triangle test.
+    const bool edge_zero = (U == 0.0f || V == 0.0f || W == 0.0f);
+    if (__ballot(edge_zero) != 0ull && edge_zero) {
       double CxBy = (double)Cx * (double)By, CyBx = (double)Cy * (double)Bx;
       U = (float)(CxBy - CyBx);
       double AxCy = (double)Ax * (double)Cy, AyCx = (double)Ay * (double)Cx;

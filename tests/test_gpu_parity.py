@@ -161,6 +161,25 @@ def test_edge_cases_empty_scene_axis_rays_degenerate_triangles(ctx, oracle):
     assert list(got["prim"][:3]) == [0, 1, 1]
 
 
+def test_non_finite_rays_miss_quickly(ctx, oracle):
+    """NaN/Inf rays (the shading can produce them: Q7 0/0, normalize(0)) are misses and must not walk the whole BVH."""
+    import time
+    sc = scenes.atrium(1)
+    ctx.scene_create(sc)
+    osc = oracle.scene(sc)
+    rays = random_rays(9, 4096, (-20, 0, -10), (20, 16, 10))
+    rays["origin"][::7, 1] = np.nan
+    rays["dir"][3::11, 0] = np.inf
+    rays["dir"][5::13] = np.nan
+    t0 = time.time()
+    got = ctx.trace_rays(rays)
+    assert time.time() - t0 < 2.0
+    want = osc.trace_rays(rays)
+    assert np.array_equal(got["prim"], want["prim"]) and np.array_equal(got["t"].view(np.uint32), want["t"].view(np.uint32))
+    bad = ~np.isfinite(rays["origin"].sum(1) + rays["dir"].sum(1))
+    assert bad.sum() > 500 and (got["prim"][bad] == api.PT_MISS).all()
+
+
 def test_tmin_tmax_exclusive_on_device(ctx, oracle):
     v = np.zeros(3, dtype=api.VERTEX_DTYPE)
     v["pos"] = [[-1, -1, 5], [1, -1, 5], [0, 1, 5]]
