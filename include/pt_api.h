@@ -187,7 +187,8 @@ enum {
   PT_OPT_COUNT_TRAVERSAL = 1, /* 0/1: run the counting instantiation of the extend kernel (fills nodes_visited/tris_tested) */
   PT_OPT_TIME_KERNELS = 2,    /* 0/1: bracket kernels with HIP events (fills extend_ms/render_ms) */
   PT_OPT_SAMPLES_PER_BATCH = 3, /* samples per pixel kept in flight per wavefront batch (0 = auto) */
-  PT_OPT_SKY_MODE = 4,        /* 0 = ray-march on every miss (reference, SampleSky.hlsl:7-47); 1 = direction LUT (extension) */
+  PT_OPT_SKY_MODE = 4,        /* 0 = ray-march on every miss (reference, SampleSky.hlsl:7-47); 1 = 256x256 direction LUT built per pt_render
+                                 for the camera position (extension after sky/compute_skyView_lut.hlsl; image relMSE vs mode 0 < 1e-4) */
   PT_OPT_EXTEND_FETCH_MIN = 5,     /* tuning: refill idle lanes of a wave once this many (1..64) are idle */
   PT_OPT_EXTEND_POSTPONE_PCT = 6,  /* tuning: postpone triangle tests while < this % of busy lanes have any (0 = never) */
   PT_OPT_EXTEND_BLOCKS_PER_CU = 7, /* tuning: persistent grid = CUs x this (0 = occupancy query) */
@@ -271,7 +272,9 @@ enum {
   PT_FN_LAMBERT = 6,           /* in: color3,N3,L3 (9)     -> out: 4   brdf3,pdf brdfSampling.hlsl:6-14 */
   PT_FN_SKY = 7,               /* in: viewPos3,viewDir3 (6)-> out: 3   SampleSkyLuminance SampleSky.hlsl:7-47 (uses consts + ctx LUT) */
   PT_FN_PRIMARY_RAY = 8,       /* in: pixel2,res2 (4)      -> out: 6   origin3,dir3 GetPrimaryRay Common.hlsl:183-189 */
-  PT_FN_COUNT = 9
+  PT_FN_SKY_VIEW_LUT = 9,      /* in: viewPos3,viewDir3 (6)-> out: 3   sky-mode-1 stand-in for PT_FN_SKY: bilinear fetch from the
+                                  direction LUT built for consts->myCameraPos (extension; viewPos only feeds the march's domain tests) */
+  PT_FN_COUNT = 10
 };
 
 #ifdef __cplusplus

@@ -38,9 +38,9 @@ PT_OPT_EXTEND_LDS_STACK = 8
 PT_OPT_EXTEND_DEFER = 9
 
 (PT_FN_RAND01, PT_FN_FRESNEL, PT_FN_SPEC_PROB, PT_FN_SAMPLE_PHONG, PT_FN_EVAL_PHONG, PT_FN_COS_HEMISPHERE,
- PT_FN_LAMBERT, PT_FN_SKY, PT_FN_PRIMARY_RAY) = range(9)
-FN_IN_WIDTH = [4, 6, 4, 6, 10, 5, 9, 6, 4]
-FN_OUT_WIDTH = [8, 1, 1, 4, 1, 3, 4, 3, 6]
+ PT_FN_LAMBERT, PT_FN_SKY, PT_FN_PRIMARY_RAY, PT_FN_SKY_VIEW_LUT) = range(10)
+FN_IN_WIDTH = [4, 6, 4, 6, 10, 5, 9, 6, 4, 6]
+FN_OUT_WIDTH = [8, 1, 1, 4, 1, 3, 4, 3, 6, 3]
 
 TLUT_W, TLUT_H = 256, 64
 

@@ -48,6 +48,8 @@ struct WavefrontBuffers {
   uint64_t capacity = 0;                  // paths
 };
 
+#define PT_SKYVIEW_TEXELS (256 * 256)   // PT_SKYVIEW_W x PT_SKYVIEW_H of sky_device.h
+
 struct LaunchCfg {
   int num_cus = 256;
   int extend_blocks = 1024;   // persistent grid of the extend kernel
@@ -66,11 +68,12 @@ void launch_extend(const DeviceScene& sc, const float4* ray_o, const float4* ray
                    uint32_t* work_cursor, unsigned long long* stats, bool count_traversal, const LaunchCfg& cfg, hipStream_t s);
 void launch_shade(const PtRtConsts& c, const DeviceScene& sc, const WavefrontBuffers& wb, int bounce, uint32_t w, uint32_t h,
                   uint32_t first_sample, uint64_t max_paths, const LaunchCfg& cfg, hipStream_t s);
-void launch_sky(const PtRtConsts& c, const uint2* lut, const WavefrontBuffers& wb, uint64_t max_paths, const LaunchCfg& cfg, hipStream_t s);
+void launch_skyview_lut(const PtRtConsts& c, const uint2* tlut, float4* out, hipStream_t s);   // out: PT_SKYVIEW_TEXELS float4
+void launch_sky(const PtRtConsts& c, const uint2* lut, const float4* skyview, const WavefrontBuffers& wb, uint64_t max_paths, const LaunchCfg& cfg, hipStream_t s);
 void launch_resolve(const WavefrontBuffers& wb, float4* accum, uint32_t w, uint32_t h, uint32_t samples_in_batch, uint32_t num_bounces,
                     hipStream_t s);
 void launch_set_count(uint32_t* counter, uint32_t value, hipStream_t s);
-void launch_debug_eval(int fn, const PtRtConsts& c, const uint2* lut, const float* in, uint64_t n, float* out, hipStream_t s);
+void launch_debug_eval(int fn, const PtRtConsts& c, const uint2* lut, const float4* skyview, const float* in, uint64_t n, float* out, hipStream_t s);
 size_t extend_lds_bytes(uint32_t stack_entries);
 int extend_occupancy_blocks(uint32_t lds_entries_total);
 

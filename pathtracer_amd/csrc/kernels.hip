@@ -19,6 +19,7 @@
 namespace pt {
 using namespace ptd;
 
+static_assert(PT_SKYVIEW_W * PT_SKYVIEW_H == PT_SKYVIEW_TEXELS, "sky-view LUT size");
 static_assert(sizeof(PtRtConsts) == 288, "RtConsts is 288 bytes (PathTracer.cpp:709-740)");
 
 // ------------------------------------------------------------------------------------------------ helpers
@@ -403,14 +404,28 @@ __global__ void __launch_bounds__(PT_SHADE_THREADS) k_shade(PtRtConsts c, Device
 }
 
 // ------------------------------------------------------------------------------------------------ sky
-__global__ void __launch_bounds__(256) k_sky(PtRtConsts c, const uint2* __restrict__ lut, const float4* __restrict__ sky_o,
+// Sky-view LUT build (PT_OPT_SKY_MODE = 1; sky_device.h): one thread per texel, rebuilt at the head of every pt_render.
+__global__ void __launch_bounds__(256) k_skyview_lut(PtRtConsts c, const uint2* __restrict__ tlut, float4* __restrict__ out) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= PT_SKYVIEW_W * PT_SKYVIEW_H) return;
+  const v3 L = SkyViewLutTexel(c, tlut, i % PT_SKYVIEW_W, i / PT_SKYVIEW_W);
+  out[i] = make_float4(L.x, L.y, L.z, 1.0f);
+}
+
+template <bool VIEW_LUT>
+__global__ void __launch_bounds__(256) k_sky(PtRtConsts c, const uint2* __restrict__ lut, const float4* __restrict__ skyview,
+                                             const float4* __restrict__ sky_o,
                                              const float4* __restrict__ sky_d, const float4* __restrict__ st_T,
                                              float4* __restrict__ st_L, const uint32_t* __restrict__ counters) {
   const uint32_t n = counters[CTR_AT(CTR_SKY)];
+  SkyViewFrame frame;
+  if (VIEW_LUT) frame = MakeSkyViewFrame(c);
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     const float4 o = sky_o[i], d = sky_d[i];
     const uint32_t pid = __float_as_uint(o.w);
-    const v3 sky = SampleSkyLuminance(mk3(o.x, o.y, o.z), mk3(d.x, d.y, d.z), c, lut);
+    v3 sky;
+    if (VIEW_LUT) sky = SampleSkyLuminanceViewLut(mk3(o.x, o.y, o.z), mk3(d.x, d.y, d.z), c, skyview, frame);
+    else sky = SampleSkyLuminance(mk3(o.x, o.y, o.z), mk3(d.x, d.y, d.z), c, lut);
     const float4 T = st_T[pid];
     float4 L = st_L[pid];
     const v3 add = mk3(T.x, T.y, T.z) * sky;
@@ -450,7 +465,7 @@ __global__ void __launch_bounds__(256) k_resolve(const float4* __restrict__ st_L
 __global__ void k_set_count(uint32_t* counter, uint32_t value) { *counter = value; }
 
 // ------------------------------------------------------------------------------------------------ debug eval
-__global__ void __launch_bounds__(256) k_debug_eval(int fn, PtRtConsts c, const uint2* __restrict__ lut,
+__global__ void __launch_bounds__(256) k_debug_eval(int fn, PtRtConsts c, const uint2* __restrict__ lut, const float4* __restrict__ skyview,
                                                     const float* __restrict__ in, uint64_t n, float* __restrict__ out) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -494,6 +509,11 @@ __global__ void __launch_bounds__(256) k_debug_eval(int fn, PtRtConsts c, const 
     case PT_FN_SKY: {
       const float* r = in + 6 * i;
       const v3 L = SampleSkyLuminance(ld3(r), ld3(r + 3), c, lut);
+      out[3 * i] = L.x; out[3 * i + 1] = L.y; out[3 * i + 2] = L.z;
+    } break;
+    case PT_FN_SKY_VIEW_LUT: {
+      const float* r = in + 6 * i;
+      const v3 L = SampleSkyLuminanceViewLut(ld3(r), ld3(r + 3), c, skyview, MakeSkyViewFrame(c));
       out[3 * i] = L.x; out[3 * i + 1] = L.y; out[3 * i + 2] = L.z;
     } break;
     case PT_FN_PRIMARY_RAY: {
@@ -571,8 +591,17 @@ void launch_shade(const PtRtConsts& c, const DeviceScene& sc, const WavefrontBuf
                      wb.qid[out], wb.sky_o, wb.sky_d, wb.counters, bounce, w, h, first_sample);
 }
 
-void launch_sky(const PtRtConsts& c, const uint2* lut, const WavefrontBuffers& wb, uint64_t max_paths, const LaunchCfg& cfg, hipStream_t s) {
-  hipLaunchKernelGGL(k_sky, dim3(grid_for(max_paths, cfg.stream_blocks)), dim3(256), 0, s, c, lut, wb.sky_o, wb.sky_d, wb.st_T, wb.st_L,
+void launch_skyview_lut(const PtRtConsts& c, const uint2* tlut, float4* out, hipStream_t s) {
+  hipLaunchKernelGGL(k_skyview_lut, dim3((PT_SKYVIEW_W * PT_SKYVIEW_H + 255) / 256), dim3(256), 0, s, c, tlut, out);
+}
+
+void launch_sky(const PtRtConsts& c, const uint2* lut, const float4* skyview, const WavefrontBuffers& wb, uint64_t max_paths, const LaunchCfg& cfg, hipStream_t s) {
+  if (skyview) {
+    hipLaunchKernelGGL(k_sky<true>, dim3(grid_for(max_paths, cfg.stream_blocks)), dim3(256), 0, s, c, lut, skyview, wb.sky_o, wb.sky_d, wb.st_T, wb.st_L,
+                       wb.counters);
+    return;
+  }
+  hipLaunchKernelGGL(k_sky<false>, dim3(grid_for(max_paths, cfg.stream_blocks)), dim3(256), 0, s, c, lut, skyview, wb.sky_o, wb.sky_d, wb.st_T, wb.st_L,
                      wb.counters);
 }
 
@@ -587,8 +616,8 @@ void launch_set_count(uint32_t* counter, uint32_t value, hipStream_t s) {
   hipLaunchKernelGGL(k_set_count, dim3(1), dim3(1), 0, s, counter, value);
 }
 
-void launch_debug_eval(int fn, const PtRtConsts& c, const uint2* lut, const float* in, uint64_t n, float* out, hipStream_t s) {
-  hipLaunchKernelGGL(k_debug_eval, dim3(grid_for(n, 0)), dim3(256), 0, s, fn, c, lut, in, n, out);
+void launch_debug_eval(int fn, const PtRtConsts& c, const uint2* lut, const float4* skyview, const float* in, uint64_t n, float* out, hipStream_t s) {
+  hipLaunchKernelGGL(k_debug_eval, dim3(grid_for(n, 0)), dim3(256), 0, s, fn, c, lut, skyview, in, n, out);
 }
 
 }  // namespace pt

@@ -35,6 +35,7 @@ struct pt_ctx {
 
   // sky
   uint2* lut = nullptr;
+  float4* skyview = nullptr;
   bool has_sky = false;
 
   // accumulation target
@@ -242,6 +243,7 @@ int pt_destroy(pt_ctx* ctx) {
   if (ctx->tmp_rays) (void)hipFree(ctx->tmp_rays);
   if (ctx->tmp_hits) (void)hipFree(ctx->tmp_hits);
   if (ctx->lut) (void)hipFree(ctx->lut);
+  if (ctx->skyview) (void)hipFree(ctx->skyview);
   if (ctx->accum && ctx->accum_owned) (void)hipFree(ctx->accum);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
   delete ctx;
@@ -273,8 +275,8 @@ int pt_set_option(pt_ctx* ctx, int option, int64_t value) {
       ctx->samples_per_batch = value;
       return PT_OK;
     case PT_OPT_SKY_MODE:
-      if (value != 0) return ctx->fail(PT_ERR_UNSUPPORTED, "only sky mode 0 (ray-march on every miss) is implemented");
-      ctx->sky_mode = 0;
+      if (value != 0 && value != 1) return ctx->fail(PT_ERR_UNSUPPORTED, "sky mode must be 0 (ray-march on every miss) or 1 (direction LUT)");
+      ctx->sky_mode = (int)value;
       return PT_OK;
     case PT_OPT_EXTEND_FETCH_MIN:
       if (value < 1 || value > 64) return ctx->fail(PT_ERR_INVALID_ARG, "fetch_min must be 1..64");
@@ -391,6 +393,11 @@ int pt_sky_set(pt_ctx* ctx, const PtAtmosphere* atmosphere) {
     PT_HIP(hipMalloc(&v, 256 * 64 * sizeof(uint2)));
     ctx->lut = (uint2*)v;
   }
+  if (!ctx->skyview) {   // direction LUT of sky mode 1 (1 MB), filled per pt_render
+    void* v = nullptr;
+    PT_HIP(hipMalloc(&v, (size_t)PT_SKYVIEW_TEXELS * sizeof(float4)));
+    ctx->skyview = (float4*)v;
+  }
   launch_transmittance_lut(*atmosphere, ctx->lut, ctx->stream);
   PT_HIP(hipGetLastError());
   ctx->has_sky = true;
@@ -503,6 +510,8 @@ int pt_render(pt_ctx* ctx, const PtRtConsts* consts, uint32_t width, uint32_t he
     PT_HIP(hipEventRecord(rev.first, ctx->stream));
   }
   const uint32_t bounces = consts->myMaxRecursionDepth + 1;  // inclusive loop bound (PathTracing.hlsl:68)
+  const bool use_skyview = ctx->sky_mode == 1 && consts->mySampleSky;
+  if (use_skyview) launch_skyview_lut(*consts, ctx->lut, ctx->skyview, ctx->stream);   // 64 Ki texels, a few microseconds
   for (uint32_t done = 0; done < num_samples;) {
     const uint32_t k = (uint32_t)std::min<uint64_t>(spb, num_samples - done);
     const uint64_t paths = wh * k;
@@ -513,7 +522,7 @@ int pt_render(pt_ctx* ctx, const PtRtConsts* consts, uint32_t width, uint32_t he
       extend_one(ctx, ctx->wb.ray_o[in], ctx->wb.ray_d[in], 1, ctx->wb.hits, ctx->wb.counters + CTR_AT(CTR_QCOUNT0 + b), ctx->wb.counters + CTR_AT(CTR_WORK0 + b), (int)b);
       launch_shade(*consts, ctx->ds, ctx->wb, (int)b, width, height, first_sample + done, paths, ctx->cfg, ctx->stream);
     }
-    if (consts->mySampleSky) launch_sky(*consts, ctx->lut, ctx->wb, paths, ctx->cfg, ctx->stream);
+    if (consts->mySampleSky) launch_sky(*consts, ctx->lut, use_skyview ? ctx->skyview : nullptr, ctx->wb, paths, ctx->cfg, ctx->stream);
     launch_resolve(ctx->wb, ctx->accum, width, height, k, bounces, ctx->stream);
     done += k;
   }
@@ -574,21 +583,22 @@ int pt_trace_rays(pt_ctx* ctx, const PtRay* rays, uint64_t num_rays, PtHit* hits
 
 int pt_debug_eval(pt_ctx* ctx, int fn, const PtRtConsts* consts, const float* in, uint64_t n, float* out) {
   PT_REQUIRE_CTX();
-  static const int in_w[PT_FN_COUNT] = {4, 6, 4, 6, 10, 5, 9, 6, 4};
-  static const int out_w[PT_FN_COUNT] = {8, 1, 1, 4, 1, 3, 4, 3, 6};
+  static const int in_w[PT_FN_COUNT] = {4, 6, 4, 6, 10, 5, 9, 6, 4, 6};
+  static const int out_w[PT_FN_COUNT] = {8, 1, 1, 4, 1, 3, 4, 3, 6, 3};
   if (fn < 0 || fn >= PT_FN_COUNT) return ctx->fail(PT_ERR_INVALID_ARG, "unknown function id");
   if (n == 0) return PT_OK;
   if (!in || !out) return ctx->fail(PT_ERR_INVALID_ARG, "null array");
   PtRtConsts c;
   if (consts) c = *consts; else memset(&c, 0, sizeof(c));
-  if (fn == PT_FN_SKY && c.mySampleSky && !ctx->has_sky) return ctx->fail(PT_ERR_NO_SKY, "pt_sky_set has not been called");
+  if ((fn == PT_FN_SKY || fn == PT_FN_SKY_VIEW_LUT) && c.mySampleSky && !ctx->has_sky) return ctx->fail(PT_ERR_NO_SKY, "pt_sky_set has not been called");
   float *d_in = nullptr, *d_out = nullptr;
   int rc;
   if ((rc = dev_alloc(ctx, &d_in, n * in_w[fn], nullptr))) return rc;
   if ((rc = dev_alloc(ctx, &d_out, n * out_w[fn], nullptr))) { (void)hipFree(d_in); return rc; }
   hipError_t e = hipMemcpyAsync(d_in, in, n * in_w[fn] * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
   if (e == hipSuccess) {
-    launch_debug_eval(fn, c, ctx->lut, d_in, n, d_out, ctx->stream);
+    if (fn == PT_FN_SKY_VIEW_LUT && c.mySampleSky) launch_skyview_lut(c, ctx->lut, ctx->skyview, ctx->stream);
+    launch_debug_eval(fn, c, ctx->lut, ctx->skyview, d_in, n, d_out, ctx->stream);
     e = hipGetLastError();
   }
   if (e == hipSuccess) e = hipMemcpyAsync(out, d_out, n * out_w[fn] * sizeof(float), hipMemcpyDeviceToHost, ctx->stream);

@@ -288,4 +288,139 @@ __device__ __forceinline__ v3 SampleSkyLuminance(v3 viewPos, v3 viewDir, const P
   return sky;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Sky-view LUT (extension, PT_OPT_SKY_MODE = 1): the marched sky radiance of SampleSkyLuminance tabulated over view
+// direction for ONE reference position (the camera), so a miss costs a bilinear fetch instead of a 14-step march.
+// Parametrisation after the reference's raster-path LUT (SkyViewLutParamsToUv / UvToSkyViewLutParams,
+// sky/Common.hlsl:119-149,290-318; compute_skyView_lut.hlsl:27-91; render_sky.hlsl:22-54): u = sqrt of the azimuth
+// term relative to the sun, v = non-linear zenith angle, split at the horizon. Differences, all deliberate: texel i
+// maps to unit coordinate i/(N-1) (the reference's half-texel helpers are not mutually inverse); the sun is placed in
+// the LUT's local frame (the reference marches with the world-space sun, which is only right for suns in the +X
+// azimuth); fp32 texels. The origin of a miss ray is replaced by the camera position: scene extents (tens of
+// metres) are negligible against the atmosphere's scale heights (1.2 / 8 km).
+// Known limit: the marched function is discontinuous in elevation wherever one of its 14 sample points crosses
+// 10 m of altitude (the earth-shadow sphere is lifted by PLANET_RADIUS_OFFSET, sky/Common.hlsl:153,519-521, so a
+// sample below 10 m counts as shadowed). For a camera near the ground that happens at ~0.3 deg and ~0 deg of
+// elevation; the table smooths each step over one row (<= 0.1 deg there). Everywhere else it tracks the march to
+// < 0.1 % (tests/test_gpu_parity.py::test_sky_view_lut_tracks_marched_sky).
+#define PT_SKYVIEW_W 256
+#define PT_SKYVIEW_H 256
+
+struct SkyViewFrame {
+  float viewHeight;      // |camera + (0,R,0)|, clamped above the ground
+  v3 up;                 // local zenith
+  float beta;            // angle between horizon and nadir-side: acos(Vhorizon / h)
+  float zenithHorizonAngle;
+  float sunZenithCos;
+  v3 sunFwd;             // unit horizontal direction towards the sun (arbitrary when the sun is at the zenith)
+  bool sunHasAzimuth;
+};
+
+__device__ __forceinline__ SkyViewFrame MakeSkyViewFrame(const PtRtConsts& c) {
+  SkyViewFrame f;
+  const float R = c.mySkyConsts.myAtmosphere.BottomRadius;
+  v3 worldPos = ld3(c.myCameraPos) + mk3(0.0f, R, 0.0f);
+  float h = length(worldPos);
+  if (!(h > R + 1.0f)) { worldPos = mk3(0.0f, R + 1.0f, 0.0f); h = R + 1.0f; }
+  f.viewHeight = h;
+  f.up = worldPos / h;
+  const float Vhorizon = sqrtf(fmaxf(0.0f, (h - R) * (h + R)));
+  f.beta = acosf(clampf(Vhorizon / h, -1.0f, 1.0f));
+  f.zenithHorizonAngle = PT_PI - f.beta;
+  const v3 sun = ld3(c.mySkyConsts.mySunDirection);
+  f.sunZenithCos = dot(f.up, sun);
+  const v3 horiz = sun - f.up * f.sunZenithCos;
+  const float hl = length(horiz);
+  f.sunHasAzimuth = hl > 1e-4f;
+  f.sunFwd = f.sunHasAzimuth ? horiz / hl : mk3(1.0f, 0.0f, 0.0f);
+  return f;
+}
+
+// texel -> radiance (one LUT entry). Local frame: y = up, x = towards the sun's azimuth.
+__device__ __forceinline__ v3 SkyViewLutTexel(const PtRtConsts& c, const uint2* __restrict__ tlut, uint32_t ix, uint32_t iy) {
+  const SkyViewFrame f = MakeSkyViewFrame(c);
+  Atmo A;
+  __builtin_memcpy(&A, &c.mySkyConsts.myAtmosphere, sizeof(A));
+  // two charts of PT_SKYVIEW_H/2 rows each: rows [0, H/2) zenith -> horizon, rows [H/2, H) horizon -> nadir; the
+  // first and last row of a chart sit exactly on its end points
+  const int half = PT_SKYVIEW_H / 2;
+  const float u = (float)ix / (float)(PT_SKYVIEW_W - 1);
+  float viewZenithCos;
+  if ((int)iy < half) {
+    float coord = (float)iy / (float)(half - 1);
+    coord = 1.0f - coord;
+    coord *= coord;
+    coord = 1.0f - coord;
+    viewZenithCos = cosf(f.zenithHorizonAngle * coord);
+  } else {
+    float coord = (float)((int)iy - half) / (float)(half - 1);
+    coord *= coord;
+    viewZenithCos = cosf(f.zenithHorizonAngle + f.beta * coord);
+  }
+  const float lightViewCos = -(u * u * 2.0f - 1.0f);
+  const float vs = sqrtf(fmaxf(0.0f, 1.0f - viewZenithCos * viewZenithCos));
+  const v3 dir = mk3(vs * lightViewCos, viewZenithCos, vs * sqrtf(fmaxf(0.0f, 1.0f - lightViewCos * lightViewCos)));
+  const float ss = sqrtf(fmaxf(0.0f, 1.0f - f.sunZenithCos * f.sunZenithCos));
+  const v3 sunLocal = mk3(ss, f.sunZenithCos, 0.0f);
+  v3 P = mk3(0.0f, f.viewHeight, 0.0f);
+  v3 L = mk3(0.0f);
+  if (MoveToTopAtmosphere(P, dir, A.TopRadius)) {
+    v2 mm; mm.x = c.mySkyConsts.myRayMarchMinMaxSPP[0]; mm.y = c.mySkyConsts.myRayMarchMinMaxSPP[1];
+    L = IntegrateSkyLuminance(P, dir, sunLocal, A, mm, ld3(c.mySkyConsts.mySunIlluminance), tlut);
+  }
+  return L;
+}
+
+// direction -> radiance by bilinear lookup (the stand-in for SampleSkyLuminance in sky mode 1)
+__device__ __forceinline__ v3 SampleSkyViewLut(const float4* __restrict__ lut, const SkyViewFrame& f, float bottomR, v3 viewDir) {
+  const float vzc = clampf(dot(viewDir, f.up), -1.0f, 1.0f);
+  float lvc = 1.0f;
+  if (f.sunHasAzimuth) {
+    const v3 hv = viewDir - f.up * vzc;
+    const float hl = length(hv);
+    if (hl > 1e-6f) lvc = clampf(dot(hv, f.sunFwd) / hl, -1.0f, 1.0f);
+  }
+  const float ang = acosf(vzc);
+  const int half = PT_SKYVIEW_H / 2;
+  float coord;
+  int row0;
+  if (ang <= f.zenithHorizonAngle) {      // above the horizon (does not intersect the ground): upper chart
+    coord = 1.0f - sqrtf(fmaxf(0.0f, 1.0f - ang / f.zenithHorizonAngle));
+    row0 = 0;
+  } else {
+    coord = sqrtf(clampf((ang - f.zenithHorizonAngle) / f.beta, 0.0f, 1.0f));
+    row0 = half;
+  }
+  const float u = sqrtf(clampf(-lvc * 0.5f + 0.5f, 0.0f, 1.0f));
+  const float x = clampf(u * (float)(PT_SKYVIEW_W - 1), 0.0f, (float)(PT_SKYVIEW_W - 1));
+  const float y = clampf(coord * (float)(half - 1), 0.0f, (float)(half - 1));   // never interpolates across the charts
+  const int x0 = (int)floorf(x), yy = (int)floorf(y);
+  const float fx = x - (float)x0, fy = y - (float)yy;
+  const int x1 = x0 + 1 < PT_SKYVIEW_W ? x0 + 1 : PT_SKYVIEW_W - 1;
+  const int y0 = row0 + yy, y1 = row0 + (yy + 1 < half ? yy + 1 : half - 1);
+  const float4 t00 = lut[y0 * PT_SKYVIEW_W + x0], t10 = lut[y0 * PT_SKYVIEW_W + x1];
+  const float4 t01 = lut[y1 * PT_SKYVIEW_W + x0], t11 = lut[y1 * PT_SKYVIEW_W + x1];
+  const float gx = 1.0f - fx, gy = 1.0f - fy;
+  (void)bottomR;
+  return mk3((t00.x * gx + t10.x * fx) * gy + (t01.x * gx + t11.x * fx) * fy,
+             (t00.y * gx + t10.y * fx) * gy + (t01.y * gx + t11.y * fx) * fy,
+             (t00.z * gx + t10.z * fx) * gy + (t01.z * gx + t11.z * fx) * fy);
+}
+
+// SampleSkyLuminance with the march replaced by the table. The march's domain tests are kept, evaluated at the real
+// ray origin: in fp32, viewPos.y + 6360000 rounds to the planet radius for y < 0.25 m, raySphereIntersectNearest then
+// returns tBottom = 0, tMax = 0 and the sky is black (SampleSky.hlsl:14, sky/Common.hlsl:388-411) — floor-level path
+// vertices see no sky in the reference, and neither do they here.
+__device__ __forceinline__ v3 SampleSkyLuminanceViewLut(v3 viewPos, v3 viewDir, const PtRtConsts& c, const float4* __restrict__ skyview,
+                                                        const SkyViewFrame& f) {
+  if (!c.mySampleSky) return ld3(c.mySkyFallbackEmission);
+  Atmo A;
+  __builtin_memcpy(&A, &c.mySkyConsts.myAtmosphere, sizeof(A));
+  v3 worldPos = viewPos + mk3(0.0f, A.BottomRadius, 0.0f);
+  if (!MoveToTopAtmosphere(worldPos, viewDir, A.TopRadius)) return mk3(0.0f);
+  float tMax;
+  if (!sky_tmax(worldPos, viewDir, A, tMax) || !(tMax > 0.0f)) return mk3(0.0f);
+  return SampleSkyViewLut(skyview, f, A.BottomRadius, viewDir);
+}
+
 }  // namespace ptd

@@ -284,6 +284,54 @@ def test_atrium_image_vs_oracle(ctx, oracle):
     assert img[..., :3].mean() > 0
 
 
+# ---------------------------------------------------------------------------------------------- sky mode 1 (extension)
+@pytest.mark.parametrize("sun_dir", [(0.0, 1.0, 0.0), (0.3, 0.8, 0.52), (-0.7, 0.12, 0.2), (0.2, 0.02, -0.9)])
+def test_sky_view_lut_tracks_marched_sky(ctx, oracle, sun_dir):
+    """PT_OPT_SKY_MODE=1 replaces SampleSkyLuminance by a 256x256 direction LUT (sky_device.h). The reference has no
+    such path in its ray-tracing pipeline, so the check is against the library's own marched sky (which is pinned to
+    the oracle in test_sky_function_matches_oracle). Tolerances: relMSE < 1e-4 over uniformly distributed sky-facing
+    directions; above 1 degree of elevation every direction within 1 % of the march. Below that the march itself
+    jumps by up to 25 % where a sample point crosses 10 m altitude (sky_device.h, "Known limit") and the table
+    smooths the step over one row, so only the aggregate bound applies there."""
+    ctx.sky_set(oracle.earth_atmosphere())
+    c = lookat_consts(64, 64, scenes.ATRIUM_CAM, sun_dir=sun_dir)
+    rng = np.random.default_rng(11)
+    n = 50000
+    d = rng.normal(size=(n, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    d[:, 1] = np.abs(d[:, 1])                         # sky-facing directions: what a miss ray in an outdoor scene has
+    rows = np.concatenate([np.tile(np.asarray(c.myCameraPos, dtype=np.float32), (n, 1)), d], axis=1).astype(np.float32)
+    march = ctx.debug_eval(api.PT_FN_SKY, rows, c).astype(np.float64)
+    lut = ctx.debug_eval(api.PT_FN_SKY_VIEW_LUT, rows, c).astype(np.float64)
+    assert np.isfinite(lut).all()
+    r = ((lut - march) ** 2).mean() / (march ** 2).mean()
+    assert r < 1e-4, (sun_dir, r)
+    high = d[:, 1] > np.sin(np.radians(1.0))
+    rel = np.abs(lut[high] - march[high]).max(axis=1) / march[high].max(axis=1)
+    assert rel.max() < 0.01, (sun_dir, rel.max())
+
+
+def test_sky_mode_1_image_matches_mode_0(ctx, oracle):
+    sc = scenes.atrium(1)
+    ctx.scene_create(sc)
+    ctx.sky_set(oracle.earth_atmosphere())
+    w, h = 240, 135
+    c = lookat_consts(w, h, scenes.ATRIUM_CAM)
+    imgs = []
+    try:
+        for mode in (0, 1):
+            ctx.set_option(api.PT_OPT_SKY_MODE, mode)
+            ctx.accum_reset(w, h)
+            ctx.render(c, w, h, 0, 4)
+            imgs.append(ctx.accum_read())
+    finally:
+        ctx.set_option(api.PT_OPT_SKY_MODE, 0)
+    assert imgs[0][..., :3].mean() > 0
+    assert rel_mse(imgs[1], imgs[0]) < 1e-4, rel_mse(imgs[1], imgs[0])
+    with pytest.raises(api.PtError):
+        ctx.set_option(api.PT_OPT_SKY_MODE, 2)
+
+
 # ---------------------------------------------------------------------------------------------- full-size properties
 def test_full_size_properties_1080p(ctx, oracle):
     """At BASELINE's full size (1920x1080 atrium) the oracle is too slow: check size-independent properties."""
