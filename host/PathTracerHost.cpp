@@ -307,7 +307,8 @@ void PathTracer::RenderRT(uint32_t aNumFrames) {
     mySkyDirty = false;
   }
   const PtRtConsts c = BuildRtConsts();
-  Check(pt_render(myCtx, &c, myOutputWidth, myOutputHeight, myNumAccumulationFrames, aNumFrames));
+  // PathTracer.cpp:680-683: myRenderAo swaps in the AO pipeline for the same dispatch
+  Check((myRenderAo ? pt_render_ao : pt_render)(myCtx, &c, myOutputWidth, myOutputHeight, myNumAccumulationFrames, aNumFrames));
   myNumAccumulationFrames += aNumFrames;
 }
 

@@ -1,7 +1,7 @@
 // pt_render_cli — headless replacement of the reference's WinMain loop (PathTracer/PathTracer_main.cpp:26-61) for the
 // path-tracing mode: load an OBJ, accumulate N frames, write a PFM.
 //   pt_render_cli scene.obj out.pfm [--spp N] [--width W] [--height H] [--cam x y z] [--depth D] [--no-sky]
-//                 [--fallback I] [--light-instance K] [--full-res] [--tonemap] [--device G]
+//                 [--fallback I] [--light-instance K] [--full-res] [--tonemap] [--device G] [--ao DIST]
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -12,14 +12,14 @@
 int main(int argc, char** argv) {
   if (argc < 3) {
     fprintf(stderr, "usage: %s scene.obj out.pfm [--spp N] [--width W] [--height H] [--cam x y z] [--depth D] [--no-sky] "
-                    "[--fallback I] [--light-instance K] [--full-res] [--tonemap] [--device G]\n", argv[0]);
+                    "[--fallback I] [--light-instance K] [--full-res] [--tonemap] [--device G] [--ao DIST]\n", argv[0]);
     return 2;
   }
   uint32_t spp = 64, w = 1280, h = 720;   // window 1280x720 (PathTracer_main.cpp:41-42)
   pth::float3 cam{1.0f, 102.0f, -30.0f};  // sceneLoadInfos[0] (PathTracer.cpp:40)
   int depth = 4, device = 0, light = 4;
-  bool sky = true, fullres = false, tonemap = false;
-  float fallback = 100.0f;
+  bool sky = true, fullres = false, tonemap = false, ao = false;
+  float fallback = 100.0f, ao_dist = 1.0f;
   for (int i = 3; i < argc; ++i) {
     auto is = [&](const char* s) { return strcmp(argv[i], s) == 0; };
     if (is("--spp") && i + 1 < argc) spp = (uint32_t)atoi(argv[++i]);
@@ -30,6 +30,7 @@ int main(int argc, char** argv) {
     else if (is("--light-instance") && i + 1 < argc) light = atoi(argv[++i]);
     else if (is("--fallback") && i + 1 < argc) fallback = (float)atof(argv[++i]);
     else if (is("--cam") && i + 3 < argc) { cam.x = (float)atof(argv[++i]); cam.y = (float)atof(argv[++i]); cam.z = (float)atof(argv[++i]); }
+    else if (is("--ao") && i + 1 < argc) { ao = true; ao_dist = (float)atof(argv[++i]); }
     else if (is("--no-sky")) sky = false;
     else if (is("--full-res")) fullres = true;
     else if (is("--tonemap")) tonemap = true;
@@ -44,6 +45,8 @@ int main(int argc, char** argv) {
     app.mySkyFallbackIntensity = fallback;
     app.myMaxRecursionDepth = depth;
     app.myLightInstanceIdx = light;
+    app.myRenderAo = ao;          // "Render AO" checkbox + "Ao Distance" (PathTracer.cpp:505-523)
+    app.myAoDistance = ao_dist;
     auto t0 = std::chrono::steady_clock::now();
     app.Update();
     app.Render(spp);

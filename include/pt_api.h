@@ -245,6 +245,16 @@ int pt_accum_read_sum(pt_ctx* ctx, float* host_rgba_sum, uint64_t* num_samples);
 int pt_render(pt_ctx* ctx, const PtRtConsts* consts, uint32_t width, uint32_t height,
               uint32_t first_sample, uint32_t num_samples);
 
+/* The reference's alternative "AO" pipeline (resources/shaders/raytracing/Ao.hlsl:39-103; selected by
+ * PathTracer::myRenderAo, PathTracer.cpp:341-370,680-683): one primary ray per pixel-sample; on a hit, 16 occlusion rays
+ * (TMin 0.01, TMax consts->myAoDistance) around the interpolated normal and L = 1 - occluded/16; on a miss the sky
+ * (SampleSkyLuminance) or the fallback emission. Same target, sample indexing and asynchrony as pt_render. */
+int pt_render_ao(pt_ctx* ctx, const PtRtConsts* consts, uint32_t width, uint32_t height, uint32_t first_sample, uint32_t num_samples);
+
+/* Occlusion query (host arrays): occluded[i] = 1 when anything is hit in (tmin, tmax), else 0. What Ao.hlsl's
+ * ClosestHitAo (:33-37) computes per AO ray; traversal stops at the first accepted intersection. */
+int pt_occluded(pt_ctx* ctx, const PtRay* rays, uint64_t num_rays, uint8_t* occluded);
+
 /* ---- parity / measurement helpers (no counterpart in the reference: TraceRay is a driver black box) ---- */
 /* Primary-ray closest hit per pixel for one sample index (RayGen lines 43-71 only). hits: w*h entries, host. */
 int pt_primary_hits(pt_ctx* ctx, const PtRtConsts* consts, uint32_t width, uint32_t height,

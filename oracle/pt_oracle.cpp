@@ -145,6 +145,49 @@ static inline float3 RayGenSample(const Scene& S, const PtRtConsts& c, const uin
   return luminance;
 }
 
+// Ao.hlsl RayGen — :39-103, one sample of one pixel (the alternative "AO" pipeline: 1 primary + 16 short rays).
+// ClosestHitPrimary (:13-26) keeps the interpolated normal as it is (no flip towards the viewer, not renormalised);
+// ClosestHitAo (:33-37) only reports that something was hit, so the AO rays need existence, not the closest hit.
+// Same Q1 deviation for the jitter as RayGenSample. AO rays: TMin 0.01, TMax myAoDistance (:79-81).
+static inline float3 RayGenAoSample(const Scene& S, const PtRtConsts& c, const uint16_t* lut, uint32_t px, uint32_t py,
+                                    uint32_t resX, uint32_t resY, uint32_t frameSeed, int brute, SampleStats& st) {
+  uint4 rngState = InitRNG(px, py, frameSeed);
+  float2 pixel = {(float)px, (float)py};
+  float jx = GetRand01(rngState);
+  float jy = GetRand01(rngState);
+  pixel.x += jx;
+  pixel.y += jy;
+  pixel.x = clampf(pixel.x, 0.0f, (float)resX);
+  pixel.y = clampf(pixel.y, 0.0f, (float)resY);
+  float3 origin, dir;
+  GetPrimaryRay(pixel, resX, resY, ld3(c.myNearPlaneCorner), ld3(c.myXAxis), ld3(c.myYAxis), ld3(c.myCameraPos), origin, dir);
+  st.rays++;
+  PtHit h = brute ? trace_brute(S, origin, 0.0f, dir, 10000.0f) : trace_bvh(S, origin, 0.0f, dir, 10000.0f, nullptr);
+  if (h.prim == PT_MISS) {
+    st.sky++;
+    return SampleSkyLuminance(origin, dir, c, lut);   // :96
+  }
+  st.hits++;
+  const uint32_t* idx = &S.tri_indices[3 * (size_t)h.prim];
+  float3 n0 = S.vertex_normal[idx[0]], n1 = S.vertex_normal[idx[1]], n2 = S.vertex_normal[idx[2]];
+  float baryZ = 1.0f - (h.u + h.v);
+  float3 hitNormal = h.u * n0 + h.v * n1 + baryZ * n2;
+  float3 hitPos = origin + dir * h.t;
+  const uint32_t numAoRays = 16;
+  uint32_t numAoHits = 0;
+  for (uint32_t i = 0u; i < numAoRays; ++i) {
+    float r0 = GetRand01(rngState);
+    float r1 = GetRand01(rngState);
+    float2 rand11 = {r0 * 2.0f - 1.0f, r1 * 2.0f - 1.0f};
+    float3 aoDir = GetHemisphereDirection(rand11, hitNormal);
+    st.rays++;
+    PtHit ah = brute ? trace_brute(S, hitPos, 0.01f, aoDir, c.myAoDistance) : trace_bvh(S, hitPos, 0.01f, aoDir, c.myAoDistance, nullptr);
+    if (ah.prim != PT_MISS) ++numAoHits;
+  }
+  float ao = 1.0f - (float)numAoHits / (float)numAoRays;
+  return f3(ao, ao, ao);
+}
+
 }  // namespace
 
 extern "C" {
@@ -347,6 +390,38 @@ void orc_render(void* s, const PtRtConsts* c, const uint16_t* lut, uint32_t w, u
   if (stats) {
     stats[0] = rays; stats[1] = hits; stats[2] = sky; stats[3] = (uint64_t)w * h * num_samples;
     stats[4] = nodes; stats[5] = tris;
+    stats[6] = (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(t1 - t0).count();
+#ifdef _OPENMP
+    stats[7] = (uint64_t)omp_get_max_threads();
+#else
+    stats[7] = 1;
+#endif
+  }
+}
+
+// The AO pipeline (Ao.hlsl) over samples [first_sample, first_sample+num_samples): accum += (L,0). No NaN scrub in the
+// reference's AO raygen (:99-102), and none here. stats as orc_render.
+void orc_render_ao(void* s, const PtRtConsts* c, const uint16_t* lut, uint32_t w, uint32_t h, uint32_t first_sample,
+                   uint32_t num_samples, float* accum_rgba, int brute, uint64_t* stats) {
+  const Scene& S = *(const Scene*)s;
+  uint64_t rays = 0, hits = 0, sky = 0;
+  auto t0 = std::chrono::steady_clock::now();
+  for (uint32_t si = 0; si < num_samples; ++si) {
+    const uint32_t seed = first_sample + si;
+#pragma omp parallel for schedule(dynamic, 2) reduction(+ : rays, hits, sky)
+    for (int y = 0; y < (int)h; ++y)
+      for (uint32_t x = 0; x < w; ++x) {
+        SampleStats st;
+        float3 L = RayGenAoSample(S, *c, lut, x, (uint32_t)y, w, h, seed, brute, st);
+        rays += st.rays; hits += st.hits; sky += st.sky;
+        float* a = &accum_rgba[((size_t)y * w + x) * 4];
+        a[0] += L.x; a[1] += L.y; a[2] += L.z;
+      }
+  }
+  auto t1 = std::chrono::steady_clock::now();
+  if (stats) {
+    stats[0] = rays; stats[1] = hits; stats[2] = sky; stats[3] = (uint64_t)w * h * num_samples;
+    stats[4] = 0; stats[5] = 0;
     stats[6] = (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(t1 - t0).count();
 #ifdef _OPENMP
     stats[7] = (uint64_t)omp_get_max_threads();

@@ -143,9 +143,11 @@ SYMBOLS = {
     "pt_accum_read": (C.c_int, [_P, _P]),
     "pt_accum_read_sum": (C.c_int, [_P, _P, C.POINTER(C.c_uint64)]),
     "pt_render": (C.c_int, [_P, C.POINTER(PtRtConsts), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
+    "pt_render_ao": (C.c_int, [_P, C.POINTER(PtRtConsts), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
     "pt_primary_hits": (C.c_int, [_P, C.POINTER(PtRtConsts), C.c_uint32, C.c_uint32, C.c_uint32, _P]),
     "pt_trace_rays": (C.c_int, [_P, _P, C.c_uint64, _P]),
     "pt_trace_rays_device": (C.c_int, [_P, _P, C.c_uint64, _P]),
+    "pt_occluded": (C.c_int, [_P, _P, C.c_uint64, _P]),
     "pt_debug_eval": (C.c_int, [_P, C.c_int, C.POINTER(PtRtConsts), _P, C.c_uint64, _P]),
     "pt_debug_read_queue": (C.c_int, [_P, C.c_uint32, _P, C.c_uint64, C.POINTER(C.c_uint64)]),
     "pt_stats_get": (C.c_int, [_P, C.POINTER(PtStats)]),

@@ -139,6 +139,9 @@ class Context:
     def render(self, consts, w, h, first_sample, num_samples):
         self._ck(self.lib.pt_render(self.h, C.byref(consts), w, h, first_sample, num_samples))
 
+    def render_ao(self, consts, w, h, first_sample, num_samples):
+        self._ck(self.lib.pt_render_ao(self.h, C.byref(consts), w, h, first_sample, num_samples))
+
     def primary_hits(self, consts, w, h, sample=0):
         out = np.empty((h, w), dtype=api.HIT_DTYPE)
         self._ck(self.lib.pt_primary_hits(self.h, C.byref(consts), w, h, sample, api.ptr(out)))
@@ -148,6 +151,12 @@ class Context:
         rays = np.ascontiguousarray(rays, dtype=api.RAY_DTYPE)
         out = np.empty(len(rays), dtype=api.HIT_DTYPE)
         self._ck(self.lib.pt_trace_rays(self.h, api.ptr(rays), len(rays), api.ptr(out)))
+        return out
+
+    def occluded(self, rays):
+        rays = np.ascontiguousarray(rays, dtype=api.RAY_DTYPE)
+        out = np.empty(len(rays), dtype=np.uint8)
+        self._ck(self.lib.pt_occluded(self.h, api.ptr(rays), len(rays), api.ptr(out)))
         return out
 
     def trace_rays_device(self, rays_ptr, n, hits_ptr):

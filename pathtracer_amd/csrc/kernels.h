@@ -28,6 +28,7 @@ enum {
   CTR_SKY = 128,        // sky-queue length
   CTR_SHADED = 129,     // ClosestHit-equivalents this batch
   CTR_MISS = 130,       // rays that hit nothing (SampleSkyLuminance calls, sky on or off)
+  CTR_AO_HITS = 131,    // AO pipeline: primary rays that hit (each spawns 16 AO rays)
   CTR_SLOTS = 132,
   CTR_WORDS = 132 * 64
 };
@@ -65,7 +66,13 @@ void launch_transmittance_lut(const PtAtmosphere& atm, uint2* lut, hipStream_t s
 void launch_generate(const PtRtConsts& c, const WavefrontBuffers& wb, uint32_t w, uint32_t h, uint32_t first_sample,
                      uint32_t samples_in_batch, hipStream_t s);
 void launch_extend(const DeviceScene& sc, const float4* ray_o, const float4* ray_d, uint32_t stride, float4* hits, const uint32_t* count,
-                   uint32_t* work_cursor, unsigned long long* stats, bool count_traversal, const LaunchCfg& cfg, hipStream_t s);
+                   uint32_t* work_cursor, unsigned long long* stats, bool count_traversal, bool any_hit, const LaunchCfg& cfg, hipStream_t s);
+// AO pipeline (Ao.hlsl): classify primaries, spawn 16 rays per primary hit into ao_o/ao_d, count occluded rays into st_L
+void launch_ao_primary(const PtRtConsts& c, const WavefrontBuffers& wb, uint64_t n_paths, const LaunchCfg& cfg, hipStream_t s);
+void launch_ao_rays(const PtRtConsts& c, const DeviceScene& sc, const WavefrontBuffers& wb, float4* ao_o, float4* ao_d, uint32_t w, uint32_t h,
+                    uint32_t first_sample, uint64_t n_paths, const LaunchCfg& cfg, hipStream_t s);
+void launch_ao_count(const WavefrontBuffers& wb, const float4* ao_hits, uint64_t n_paths, const LaunchCfg& cfg, hipStream_t s);
+void launch_hit_flags(const float4* hits, uint64_t n, uint8_t* flags, hipStream_t s);
 void launch_shade(const PtRtConsts& c, const DeviceScene& sc, const WavefrontBuffers& wb, int bounce, uint32_t w, uint32_t h,
                   uint32_t first_sample, uint64_t max_paths, const LaunchCfg& cfg, hipStream_t s);
 void launch_skyview_lut(const PtRtConsts& c, const uint2* tlut, float4* out, hipStream_t s);   // out: PT_SKYVIEW_TEXELS float4

@@ -127,7 +127,9 @@ __global__ void __launch_bounds__(256) k_extend(const uint4* __restrict__ nodes,
                                                 float4* __restrict__ hits, const uint32_t* __restrict__ count_ptr,
                                                 uint32_t* __restrict__ work_cursor, unsigned long long* __restrict__ stats,
                                                 uint32_t lds_entries, uint32_t spill_entries, uint2* __restrict__ spill, uint32_t stride, uint32_t fetch_min,
-                                                uint32_t postpone_pct, uint32_t dq_entries) {
+                                                uint32_t postpone_pct, uint32_t dq_entries, uint32_t any_hit) {
+  // any_hit (wave-uniform): a ray ends at the first accepted intersection (occlusion queries: Ao.hlsl's ClosestHitAo
+  // only reports that something was hit). Only "prim != miss" is then defined in the hit record.
   extern __shared__ uint2 s_stack[];
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   LaneStack stk;
@@ -219,6 +221,7 @@ __global__ void __launch_bounds__(256) k_extend(const uint4* __restrict__ nodes,
           if (COUNT) ++n_tris;
         }
       }
+      if (any_hit && busy && tr.best.prim != 0xFFFFFFFFu) { tr.ng.y = 0u; tr.tg.y = 0u; tr.sp = 0; }
       if (busy && !tr.has_node_work()) {
         if (tr.sp == 0) {
           HitRec hr = tr.best;
@@ -259,6 +262,7 @@ __global__ void __launch_bounds__(256) k_extend(const uint4* __restrict__ nodes,
         }
         if (busy && tr.tg.y != 0u) { dq[dqn * 64u] = tr.tg; ++dqn; tr.tg.y = 0u; }   // park what is left (room is guaranteed)
       }
+      if (any_hit && busy && tr.best.prim != 0xFFFFFFFFu) { tr.ng.y = 0u; tr.tg.y = 0u; tr.sp = 0; dqn = 0u; }
       if (busy && !tr.has_node_work()) {
         if (tr.sp != 0) {
           --tr.sp;
@@ -434,6 +438,107 @@ __global__ void __launch_bounds__(256) k_sky(PtRtConsts c, const uint2* __restri
   }
 }
 
+// ------------------------------------------------------------------------------------------------ AO pipeline
+// Ao.hlsl RayGen :39-103 as a wavefront: generate -> extend (closest) -> k_ao_primary -> k_ao_rays -> extend (any hit)
+// -> k_ao_count -> k_sky -> k_resolve.
+// k_ao_primary: primaries that hit are appended to the hit list (qid), misses go to the sky queue (:96).
+__global__ void __launch_bounds__(PT_SHADE_THREADS) k_ao_primary(PtRtConsts c, const float4* __restrict__ ray_o,
+                                                                 const float4* __restrict__ ray_d, const float4* __restrict__ hits,
+                                                                 float4* __restrict__ st_L, uint32_t* __restrict__ qid_out,
+                                                                 float4* __restrict__ sky_o, float4* __restrict__ sky_d,
+                                                                 uint32_t* __restrict__ counters) {
+  const uint32_t n = counters[CTR_AT(CTR_QCOUNT0)];
+  __shared__ BlockAppendLds s_app;
+  const uint32_t lane = threadIdx.x & 63u;
+  uint32_t shaded_local = 0u, miss_local = 0u;
+  int parity = 0;
+  for (uint32_t j0 = blockIdx.x * blockDim.x; j0 < n; j0 += gridDim.x * blockDim.x, parity ^= 1) {
+    const uint32_t j = j0 + threadIdx.x;
+    bool want_hit = false, want_sky = false;
+    if (j < n) {
+      if (__float_as_uint(hits[j].w) == 0xFFFFFFFFu) {
+        ++miss_local;
+        if (c.mySampleSky) want_sky = true;
+        else st_L[j] = make_float4(c.mySkyFallbackEmission[0], c.mySkyFallbackEmission[1], c.mySkyFallbackEmission[2], 0.0f);
+      } else {
+        ++shaded_local;
+        want_hit = true;
+      }
+    }
+    uint32_t slot, sslot;
+    block_append2(s_app, parity, &counters[CTR_AT(CTR_AO_HITS)], want_hit, &counters[CTR_AT(CTR_SKY)], want_sky, slot, sslot);
+    if (want_hit) qid_out[slot] = j;
+    if (want_sky) {
+      const float4 o = ray_o[j], d = ray_d[j];
+      sky_o[sslot] = make_float4(o.x, o.y, o.z, __uint_as_float(j));
+      sky_d[sslot] = make_float4(d.x, d.y, d.z, 0.0f);
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    shaded_local += (uint32_t)__shfl_down((int)shaded_local, off);
+    miss_local += (uint32_t)__shfl_down((int)miss_local, off);
+  }
+  if (lane == 0u && shaded_local) atomicAdd(&counters[CTR_AT(CTR_SHADED)], shaded_local);
+  if (lane == 0u && miss_local) atomicAdd(&counters[CTR_AT(CTR_MISS)], miss_local);
+}
+
+// k_ao_rays: one thread per AO ray (16 per primary hit). ClosestHitPrimary (:13-26): interpolated normal as loaded
+// (no flip, not renormalised), hitPos = O + D*t. The RNG is counter based (Random.hlsl:96-99), so ray i takes draws
+// number 3+2i and 4+2i of the pixel's stream directly (draws 1,2 were the jitter).
+#define PT_AO_RAYS 16u
+__global__ void __launch_bounds__(256) k_ao_rays(PtRtConsts c, DeviceScene sc, const float4* __restrict__ ray_o,
+                                                 const float4* __restrict__ ray_d, const float4* __restrict__ hits,
+                                                 const uint32_t* __restrict__ qid, float4* __restrict__ ao_o,
+                                                 float4* __restrict__ ao_d, uint32_t* __restrict__ counters, uint32_t w,
+                                                 uint32_t h, uint32_t first_sample) {
+  const uint32_t n = counters[CTR_AT(CTR_AO_HITS)] * PT_AO_RAYS;
+  if (blockIdx.x == 0 && threadIdx.x == 0) counters[CTR_AT(CTR_QCOUNT0 + 1)] = n;   // the AO-ray queue length
+  const uint32_t wh = w * h;
+  for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gridDim.x * blockDim.x) {
+    const uint32_t pid = qid[t / PT_AO_RAYS], i = t % PT_AO_RAYS;
+    const float4 ro = ray_o[pid], rd = ray_d[pid], hr = hits[pid];
+    const uint4 pd = sc.prim_data[__float_as_uint(hr.w)];
+    const float4 n0 = sc.vertex_normal[pd.x], n1 = sc.vertex_normal[pd.y], n2 = sc.vertex_normal[pd.z];
+    const float bu = hr.y, bv = hr.z;
+    const float baryZ = 1.0f - (bu + bv);
+    const v3 hitNormal = bu * mk3(n0.x, n0.y, n0.z) + bv * mk3(n1.x, n1.y, n1.z) + baryZ * mk3(n2.x, n2.y, n2.z);
+    const v3 hitPos = mk3(ro.x, ro.y, ro.z) + mk3(rd.x, rd.y, rd.z) * hr.x;
+    Rng rng;
+    const uint32_t pix = pid % wh;
+    rng.x = pix % w; rng.y = pix / w; rng.z = first_sample + pid / wh; rng.w = 2u + 2u * i;
+    v2 rand11;
+    rand11.x = GetRand01(rng) * 2.0f - 1.0f;
+    rand11.y = GetRand01(rng) * 2.0f - 1.0f;
+    const v3 dir = GetHemisphereDirection(rand11, hitNormal);
+    ao_o[t] = make_float4(hitPos.x, hitPos.y, hitPos.z, 0.01f);        // TMin 0.01 (:79)
+    ao_d[t] = make_float4(dir.x, dir.y, dir.z, c.myAoDistance);        // TMax myAoDistance (:81)
+  }
+}
+
+// k_ao_count: one thread per AO ray; the 16 rays of a primary hit sit in a quarter wave. ao = 1 - hits/16 (:91-92).
+__global__ void __launch_bounds__(256) k_ao_count(const float4* __restrict__ ao_hits, const uint32_t* __restrict__ qid,
+                                                  float4* __restrict__ st_L, const uint32_t* __restrict__ counters) {
+  const uint32_t n = counters[CTR_AT(CTR_QCOUNT0 + 1)];
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wave_global = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, total_waves = (gridDim.x * blockDim.x) >> 6;
+  for (uint32_t base = wave_global * 64u; base < n; base += total_waves * 64u) {   // wave-uniform trip count
+    const uint32_t t = base + lane;
+    const bool occluded = t < n && __float_as_uint(ao_hits[t].w) != 0xFFFFFFFFu;
+    const unsigned long long m = __ballot(occluded);
+    if ((lane % PT_AO_RAYS) == 0u && t < n) {
+      const uint32_t numAoHits = (uint32_t)__popcll((m >> lane) & 0xFFFFull);
+      const float ao = 1.0f - (float)numAoHits / (float)PT_AO_RAYS;
+      st_L[qid[t / PT_AO_RAYS]] = make_float4(ao, ao, ao, 0.0f);
+    }
+  }
+}
+
+// hit records -> one byte per ray (1 = something was hit): the output format of occlusion queries
+__global__ void __launch_bounds__(256) k_hit_flags(const float4* __restrict__ hits, uint64_t n, uint8_t* __restrict__ flags) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) flags[i] = __float_as_uint(hits[i].w) != 0xFFFFFFFFu ? 1 : 0;
+}
+
 // ------------------------------------------------------------------------------------------------ resolve
 // PathTracing.hlsl:130-137 per sample, in sample-index order; the target keeps the SUM (pt_api.h header).
 __global__ void __launch_bounds__(256) k_resolve(const float4* __restrict__ st_L, float4* __restrict__ accum, uint32_t wh,
@@ -556,7 +661,7 @@ int extend_occupancy_blocks(uint32_t stack_entries) {
 
 static size_t g_extend_lds_granted = 0;
 void launch_extend(const DeviceScene& sc, const float4* ray_o, const float4* ray_d, uint32_t stride, float4* hits, const uint32_t* count,
-                   uint32_t* work_cursor, unsigned long long* stats, bool count_traversal, const LaunchCfg& cfg, hipStream_t s) {
+                   uint32_t* work_cursor, unsigned long long* stats, bool count_traversal, bool any_hit, const LaunchCfg& cfg, hipStream_t s) {
   const uint32_t lds_entries = sc.stack_entries < cfg.lds_stack_entries ? sc.stack_entries : cfg.lds_stack_entries;
   const uint32_t spill_entries = sc.stack_entries - lds_entries;
   const uint32_t dq = cfg.defer_entries;
@@ -570,7 +675,7 @@ void launch_extend(const DeviceScene& sc, const float4* ray_o, const float4* ray
   }
 #define PT_LAUNCH_EXTEND(C, D)                                                                                              \
   hipLaunchKernelGGL((k_extend<C, D>), dim3(cfg.extend_blocks), dim3(256), lds, s, sc.nodes, sc.tris, ray_o, ray_d, hits, count, \
-                     work_cursor, stats, lds_entries, spill_entries, sc.spill, stride, cfg.fetch_min, cfg.postpone_pct, dq)
+                     work_cursor, stats, lds_entries, spill_entries, sc.spill, stride, cfg.fetch_min, cfg.postpone_pct, dq, any_hit ? 1u : 0u)
   if (dq > 0) {
     if (count_traversal) PT_LAUNCH_EXTEND(true, true); else PT_LAUNCH_EXTEND(false, true);
   } else {
@@ -589,6 +694,28 @@ void launch_shade(const PtRtConsts& c, const DeviceScene& sc, const WavefrontBuf
   hipLaunchKernelGGL(k_shade, dim3((unsigned)g), dim3(PT_SHADE_THREADS), 0, s, c, sc, wb.ray_o[in], wb.ray_d[in],
                      bounce == 0 ? (const uint32_t*)nullptr : wb.qid[in], wb.hits, wb.st_T, wb.st_L, wb.ray_o[out], wb.ray_d[out],
                      wb.qid[out], wb.sky_o, wb.sky_d, wb.counters, bounce, w, h, first_sample);
+}
+
+void launch_ao_primary(const PtRtConsts& c, const WavefrontBuffers& wb, uint64_t n_paths, const LaunchCfg& cfg, hipStream_t s) {
+  uint64_t g = (n_paths + PT_SHADE_THREADS - 1) / PT_SHADE_THREADS;
+  const uint64_t cap = (uint64_t)cfg.num_cus * 2u;
+  g = g > cap ? cap : (g < 1 ? 1 : g);
+  hipLaunchKernelGGL(k_ao_primary, dim3((unsigned)g), dim3(PT_SHADE_THREADS), 0, s, c, wb.ray_o[0], wb.ray_d[0], wb.hits, wb.st_L, wb.qid[0],
+                     wb.sky_o, wb.sky_d, wb.counters);
+}
+
+void launch_ao_rays(const PtRtConsts& c, const DeviceScene& sc, const WavefrontBuffers& wb, float4* ao_o, float4* ao_d, uint32_t w, uint32_t h,
+                    uint32_t first_sample, uint64_t n_paths, const LaunchCfg& cfg, hipStream_t s) {
+  hipLaunchKernelGGL(k_ao_rays, dim3(grid_for(n_paths * PT_AO_RAYS, cfg.stream_blocks)), dim3(256), 0, s, c, sc, wb.ray_o[0], wb.ray_d[0], wb.hits,
+                     wb.qid[0], ao_o, ao_d, wb.counters, w, h, first_sample);
+}
+
+void launch_ao_count(const WavefrontBuffers& wb, const float4* ao_hits, uint64_t n_paths, const LaunchCfg& cfg, hipStream_t s) {
+  hipLaunchKernelGGL(k_ao_count, dim3(grid_for(n_paths * PT_AO_RAYS, cfg.stream_blocks)), dim3(256), 0, s, ao_hits, wb.qid[0], wb.st_L, wb.counters);
+}
+
+void launch_hit_flags(const float4* hits, uint64_t n, uint8_t* flags, hipStream_t s) {
+  hipLaunchKernelGGL(k_hit_flags, dim3(grid_for(n, 0)), dim3(256), 0, s, hits, n, flags);
 }
 
 void launch_skyview_lut(const PtRtConsts& c, const uint2* tlut, float4* out, hipStream_t s) {

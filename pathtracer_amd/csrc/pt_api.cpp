@@ -47,6 +47,10 @@ struct pt_ctx {
   // wavefront state
   WavefrontBuffers wb;
   std::vector<void*> wb_allocs;
+  float4* ao_o = nullptr;       // AO pipeline: 16 rays per pixel-sample (origin,tmin / dir,tmax / hit records)
+  float4* ao_d = nullptr;
+  float4* ao_hits = nullptr;
+  uint64_t ao_capacity = 0;
   float4* tmp_rays = nullptr;   // staging for pt_trace_rays (AoS PtRay)
   float4* tmp_hits = nullptr;
   uint64_t tmp_capacity = 0;
@@ -171,11 +175,29 @@ int ensure_tmp(pt_ctx* ctx, uint64_t rays) {
   PT_HIP(hipStreamSynchronize(ctx->stream));
   if (ctx->tmp_rays) (void)hipFree(ctx->tmp_rays);
   if (ctx->tmp_hits) (void)hipFree(ctx->tmp_hits);
+  if (ctx->ao_o) (void)hipFree(ctx->ao_o);
+  if (ctx->ao_d) (void)hipFree(ctx->ao_d);
+  if (ctx->ao_hits) (void)hipFree(ctx->ao_hits);
   ctx->tmp_rays = nullptr; ctx->tmp_hits = nullptr; ctx->tmp_capacity = 0;
   int rc;
   if ((rc = dev_alloc(ctx, &ctx->tmp_rays, rays * 2, nullptr))) return rc;
   if ((rc = dev_alloc(ctx, &ctx->tmp_hits, rays, nullptr))) return rc;
   ctx->tmp_capacity = rays;
+  return PT_OK;
+}
+
+int ensure_ao(pt_ctx* ctx, uint64_t rays) {
+  if (ctx->ao_capacity >= rays) return PT_OK;
+  PT_HIP(hipStreamSynchronize(ctx->stream));
+  if (ctx->ao_o) (void)hipFree(ctx->ao_o);
+  if (ctx->ao_d) (void)hipFree(ctx->ao_d);
+  if (ctx->ao_hits) (void)hipFree(ctx->ao_hits);
+  ctx->ao_o = ctx->ao_d = ctx->ao_hits = nullptr; ctx->ao_capacity = 0;
+  int rc;
+  if ((rc = dev_alloc(ctx, &ctx->ao_o, rays, nullptr))) return rc;
+  if ((rc = dev_alloc(ctx, &ctx->ao_d, rays, nullptr))) return rc;
+  if ((rc = dev_alloc(ctx, &ctx->ao_hits, rays, nullptr))) return rc;
+  ctx->ao_capacity = rays;
   return PT_OK;
 }
 
@@ -186,13 +208,14 @@ int check_consts(pt_ctx* ctx, const PtRtConsts* c, bool need_sky) {
   return PT_OK;
 }
 
-void extend_one(pt_ctx* ctx, const float4* ro, const float4* rd, uint32_t stride, float4* hits, const uint32_t* count, uint32_t* cursor, int bounce = 0) {
+void extend_one(pt_ctx* ctx, const float4* ro, const float4* rd, uint32_t stride, float4* hits, const uint32_t* count, uint32_t* cursor, int bounce = 0,
+                bool any_hit = false) {
   std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
   if (ctx->time_kernels) {
     ev = get_event_pair(ctx);
     (void)hipEventRecord(ev.first, ctx->stream);
   }
-  launch_extend(ctx->ds, ro, rd, stride, hits, count, cursor, ctx->wb.stats, ctx->count_traversal, ctx->cfg, ctx->stream);
+  launch_extend(ctx->ds, ro, rd, stride, hits, count, cursor, ctx->wb.stats, ctx->count_traversal, any_hit, ctx->cfg, ctx->stream);
   ctx->extend_launches++;
   if (ctx->time_kernels) {
     (void)hipEventRecord(ev.second, ctx->stream);
@@ -535,6 +558,48 @@ int pt_render(pt_ctx* ctx, const PtRtConsts* consts, uint32_t width, uint32_t he
   return PT_OK;
 }
 
+int pt_render_ao(pt_ctx* ctx, const PtRtConsts* consts, uint32_t width, uint32_t height, uint32_t first_sample, uint32_t num_samples) {
+  PT_REQUIRE_CTX();
+  int rc = check_consts(ctx, consts, true);
+  if (rc != PT_OK) return rc;
+  if (!ctx->has_scene) return ctx->fail(PT_ERR_NO_SCENE, "pt_render_ao before pt_scene_create");
+  if (!ctx->accum) return ctx->fail(PT_ERR_NO_TARGET, "pt_render_ao before pt_accum_reset / pt_accum_bind");
+  if (width != ctx->width || height != ctx->height) return ctx->fail(PT_ERR_SIZE_MISMATCH, "w,h differ from the accumulation target");
+  if (num_samples == 0) return PT_OK;
+  if ((uint64_t)first_sample + num_samples > 0xFFFFFFFFull) return ctx->fail(PT_ERR_INVALID_ARG, "sample index overflows 32 bits");
+  const uint64_t wh = (uint64_t)width * height;
+  if (wh * 16u >= (1ull << 31)) return ctx->fail(PT_ERR_INVALID_ARG, "w*h*16 AO rays must stay below 2^31");
+  if ((rc = ensure_wavefront(ctx, wh)) != PT_OK) return rc;
+  if ((rc = ensure_ao(ctx, wh * 16u)) != PT_OK) return rc;
+
+  std::pair<hipEvent_t, hipEvent_t> rev{nullptr, nullptr};
+  if (ctx->time_kernels) {
+    rev = get_event_pair(ctx);
+    PT_HIP(hipEventRecord(rev.first, ctx->stream));
+  }
+  const bool use_skyview = ctx->sky_mode == 1 && consts->mySampleSky;
+  if (use_skyview) launch_skyview_lut(*consts, ctx->lut, ctx->skyview, ctx->stream);
+  for (uint32_t s = 0; s < num_samples; ++s) {   // one reference frame (1 primary + <=16 AO rays per pixel) per batch
+    PT_HIP(hipMemsetAsync(ctx->wb.counters, 0, CTR_WORDS * sizeof(uint32_t), ctx->stream));
+    launch_generate(*consts, ctx->wb, width, height, first_sample + s, 1, ctx->stream);
+    extend_one(ctx, ctx->wb.ray_o[0], ctx->wb.ray_d[0], 1, ctx->wb.hits, ctx->wb.counters + CTR_AT(CTR_QCOUNT0), ctx->wb.counters + CTR_AT(CTR_WORK0), 0);
+    launch_ao_primary(*consts, ctx->wb, wh, ctx->cfg, ctx->stream);
+    launch_ao_rays(*consts, ctx->ds, ctx->wb, ctx->ao_o, ctx->ao_d, width, height, first_sample + s, wh, ctx->cfg, ctx->stream);
+    extend_one(ctx, ctx->ao_o, ctx->ao_d, 1, ctx->ao_hits, ctx->wb.counters + CTR_AT(CTR_QCOUNT0 + 1), ctx->wb.counters + CTR_AT(CTR_WORK0 + 1), 1,
+               /*any_hit=*/true);
+    launch_ao_count(ctx->wb, ctx->ao_hits, wh, ctx->cfg, ctx->stream);
+    if (consts->mySampleSky) launch_sky(*consts, ctx->lut, use_skyview ? ctx->skyview : nullptr, ctx->wb, wh, ctx->cfg, ctx->stream);
+    launch_resolve(ctx->wb, ctx->accum, width, height, 1, 2, ctx->stream);
+  }
+  PT_HIP(hipGetLastError());
+  if (ctx->time_kernels) {
+    PT_HIP(hipEventRecord(rev.second, ctx->stream));
+    ctx->render_events.push_back(rev);
+  }
+  ctx->num_samples += num_samples;
+  return PT_OK;
+}
+
 int pt_primary_hits(pt_ctx* ctx, const PtRtConsts* consts, uint32_t width, uint32_t height, uint32_t sample, PtHit* hits) {
   PT_REQUIRE_CTX();
   int rc = check_consts(ctx, consts, false);
@@ -577,6 +642,28 @@ int pt_trace_rays(pt_ctx* ctx, const PtRay* rays, uint64_t num_rays, PtHit* hits
   PT_HIP(hipMemcpyAsync(ctx->tmp_rays, rays, num_rays * sizeof(PtRay), hipMemcpyHostToDevice, ctx->stream));
   if ((rc = pt_trace_rays_device(ctx, (const PtRay*)ctx->tmp_rays, num_rays, (PtHit*)ctx->tmp_hits)) != PT_OK) return rc;
   PT_HIP(hipMemcpyAsync(hits, ctx->tmp_hits, num_rays * sizeof(PtHit), hipMemcpyDeviceToHost, ctx->stream));
+  PT_HIP(hipStreamSynchronize(ctx->stream));
+  return PT_OK;
+}
+
+int pt_occluded(pt_ctx* ctx, const PtRay* rays, uint64_t num_rays, uint8_t* occluded) {
+  PT_REQUIRE_CTX();
+  if (!ctx->has_scene) return ctx->fail(PT_ERR_NO_SCENE, "pt_occluded before pt_scene_create");
+  if (num_rays == 0) return PT_OK;
+  if (!rays || !occluded || num_rays >= (1ull << 31)) return ctx->fail(PT_ERR_INVALID_ARG, "bad arguments");
+  int rc;
+  if ((rc = ensure_tmp(ctx, num_rays)) != PT_OK) return rc;
+  if ((rc = ensure_wavefront(ctx, 1)) != PT_OK) return rc;
+  PT_HIP(hipMemcpyAsync(ctx->tmp_rays, rays, num_rays * sizeof(PtRay), hipMemcpyHostToDevice, ctx->stream));
+  PT_HIP(hipMemsetAsync(ctx->wb.counters, 0, CTR_WORDS * sizeof(uint32_t), ctx->stream));
+  launch_set_count(ctx->wb.counters + CTR_AT(CTR_QCOUNT0), (uint32_t)num_rays, ctx->stream);
+  const float4* base = (const float4*)ctx->tmp_rays;
+  extend_one(ctx, base, base + 1, 2, ctx->tmp_hits, ctx->wb.counters + CTR_AT(CTR_QCOUNT0), ctx->wb.counters + CTR_AT(CTR_WORK0), 0, /*any_hit=*/true);
+  // flags are written over the front of the ray staging buffer (already consumed), then copied out
+  uint8_t* d_flags = (uint8_t*)ctx->tmp_rays;
+  launch_hit_flags(ctx->tmp_hits, num_rays, d_flags, ctx->stream);
+  PT_HIP(hipGetLastError());
+  PT_HIP(hipMemcpyAsync(occluded, d_flags, num_rays, hipMemcpyDeviceToHost, ctx->stream));
   PT_HIP(hipStreamSynchronize(ctx->stream));
   return PT_OK;
 }

@@ -70,6 +70,13 @@ __device__ __forceinline__ v3 TransformToNormalFrame(v3 N, v3 dir) {
   v3 x = cross(z, N);
   return mk3(dot(x, dir), dot(N, dir), dot(z, dir));
 }
+// GetHemisphereDirection — Common.hlsl:159-166 (used by Ao.hlsl only); tangent/bitangent as in GetCoordinateFrame
+__device__ __forceinline__ v3 GetHemisphereDirection(v2 rand11, v3 N) {
+  v3 side = fabsf(N.x) < 0.999f ? mk3(1.0f, 0.0f, 0.0f) : mk3(0.0f, 0.0f, 1.0f);
+  v3 z = normalize(cross(-N, -side));
+  v3 x = cross(z, N);
+  return normalize(N + x * rand11.x + z * rand11.y);
+}
 
 // ---- brdfSampling.hlsl ----
 // GetLambertianBRDF / GetLambertianPDF — brdfSampling.hlsl:6-14

@@ -203,7 +203,9 @@ class PathTracer:
             self.mySky.ComputeTranmittanceLut()                              # PathTracer.cpp:580
             self._sky_dirty = False
         consts = self.BuildRtConsts()
-        self.ctx.render(consts, self.myOutputWidth, self.myOutputHeight, self.myNumAccumulationFrames, int(aNumFrames))
+        # PathTracer.cpp:680-683: myRenderAo selects the AO pipeline state + shader table for the same dispatch
+        render = self.ctx.render_ao if self.myRenderAo else self.ctx.render
+        render(consts, self.myOutputWidth, self.myOutputHeight, self.myNumAccumulationFrames, int(aNumFrames))
         self.myNumAccumulationFrames += int(aNumFrames)
 
     Render = RenderRT

@@ -46,6 +46,7 @@ def load():
     lib.orc_primary_hits.argtypes = [P, C.POINTER(api.PtRtConsts), C.c_uint32, C.c_uint32, C.c_uint32, P, C.c_int, P]
     lib.orc_render.argtypes = [P, C.POINTER(api.PtRtConsts), P, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, P,
                                C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_int, P, P]
+    lib.orc_render_ao.argtypes = [P, C.POINTER(api.PtRtConsts), P, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, P, C.c_int, P]
     lib.orc_eval.restype = C.c_int
     lib.orc_eval.argtypes = [C.c_int, C.POINTER(api.PtRtConsts), P, P, C.c_uint64, P]
     lib.orc_transmittance_lut.argtypes = [C.POINTER(api.PtAtmosphere), P]
@@ -111,6 +112,17 @@ class OracleScene:
                             api.ptr(ps) if per_sample else None)
         keys = ("rays", "shaded_hits", "sky_misses", "samples", "nodes", "tris", "ns", "threads")
         return accum, dict(zip(keys, (int(x) for x in stats))), ps
+
+    def render_ao(self, consts, w, h, first_sample, num_samples, lut=None, accum=None, brute=False):
+        """The Ao.hlsl pipeline: returns (accum[h,w,4] sum of samples, stats dict)."""
+        if accum is None:
+            accum = np.zeros((h, w, 4), dtype=np.float32)
+        stats = np.zeros(8, dtype=np.uint64)
+        lut_p = api.ptr(np.ascontiguousarray(lut)) if lut is not None else None
+        self.lib.orc_render_ao(self.h, C.byref(consts), lut_p, w, h, first_sample, num_samples, api.ptr(accum), int(brute),
+                               api.ptr(stats))
+        keys = ("rays", "shaded_hits", "sky_misses", "samples", "nodes", "tris", "ns", "threads")
+        return accum, dict(zip(keys, (int(x) for x in stats)))
 
 
 class Oracle:

@@ -284,6 +284,64 @@ def test_atrium_image_vs_oracle(ctx, oracle):
     assert img[..., :3].mean() > 0
 
 
+# ---------------------------------------------------------------------------------------------- AO pipeline (Ao.hlsl)
+def test_occlusion_queries_match_oracle_closest_hit(ctx, oracle):
+    """pt_occluded stops at the first accepted intersection; the answer must equal 'the closest-hit query hit
+    something' for every ray (bit-exact: it is a boolean of the same watertight tests)."""
+    for sc, n, tmax in ((scenes.random_triangle_soup(5, 20000), 100000, 3.0), (scenes.atrium(1), 200000, 2.5)):
+        ctx.scene_create(sc)
+        osc = oracle.scene(sc)
+        info = ctx.scene_info()
+        rays = random_rays(9, n, list(info.bounds_min), list(info.bounds_max), tmin=0.01, tmax=tmax)
+        occ = ctx.occluded(rays)
+        ref = osc.trace_rays(rays)["prim"] != api.PT_MISS
+        assert 0.02 < ref.mean() < 0.98
+        assert np.array_equal(occ.astype(bool), ref)
+        full = ctx.trace_rays(rays)["prim"] != api.PT_MISS      # closest-hit kernel path on the same rays
+        assert np.array_equal(full, ref)
+
+
+@pytest.mark.parametrize("scene_name", ["cornell", "atrium"])
+def test_ao_pipeline_matches_oracle(ctx, oracle, cornell, scene_name):
+    """Ao.hlsl: 1 primary + 16 occlusion rays. AO pixels are k/16 and must be bit-identical; sky pixels follow the
+    float tolerance of the sky march."""
+    atm = oracle.earth_atmosphere()
+    ctx.sky_set(atm)
+    olut = oracle.transmittance_lut(atm)
+    if scene_name == "cornell":
+        sc, osc = cornell
+        w, h, spp = 96, 96, 3
+        c = cornell_consts(w, h, sky=True)
+        c.myAoDistance = 40.0            # the box is ~55 units wide
+    else:
+        sc = scenes.atrium(1)
+        osc = oracle.scene(sc)
+        w, h, spp = 160, 90, 2
+        c = lookat_consts(w, h, scenes.ATRIUM_CAM)
+        c.myAoDistance = 1.0             # reference default (PathTracer.h:112)
+    ctx.scene_create(sc)
+    ctx.accum_reset(w, h)
+    ctx.stats_reset()
+    ctx.render_ao(c, w, h, 5, spp)
+    img, n = ctx.accum_read_sum()
+    st = ctx.stats()
+    acc, ost = osc.render_ao(c, w, h, 5, spp, lut=olut)
+    assert n == spp
+    assert (st.rays, st.shaded_hits, st.sky_misses) == (ost["rays"], ost["shaded_hits"], ost["sky_misses"])
+    hit_all = oracle_all_samples_hit(osc, c, w, h, 5, spp)
+    assert hit_all.any()
+    assert np.array_equal(img[hit_all], acc[hit_all])            # pure AO pixels: exact
+    assert 0.0 < acc[hit_all][:, 0].mean() / spp < 1.0           # some occlusion, not all
+    assert rel_mse(img, acc) < 1e-6
+
+
+def oracle_all_samples_hit(osc, c, w, h, first, spp):
+    m = np.ones((h, w), dtype=bool)
+    for s in range(first, first + spp):
+        m &= osc.primary_hits(c, w, h, s)["prim"] != api.PT_MISS
+    return m
+
+
 # ---------------------------------------------------------------------------------------------- sky mode 1 (extension)
 @pytest.mark.parametrize("sun_dir", [(0.0, 1.0, 0.0), (0.3, 0.8, 0.52), (-0.7, 0.12, 0.2), (0.2, 0.02, -0.9)])
 def test_sky_view_lut_tracks_marched_sky(ctx, oracle, sun_dir):

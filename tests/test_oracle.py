@@ -208,3 +208,23 @@ def test_oracle_rejects_bad_indices(oracle):
     sc = SceneData([(v, np.arange(3, dtype=np.uint32))], [(0, 3, None)], [((0, 0, 0), (1, 1, 1, 1))])
     with pytest.raises(ValueError):
         oracle.scene(sc)
+
+
+def test_ao_pipeline_bvh_equals_brute_force_and_counts(oracle):
+    """Ao.hlsl restatement: BVH and brute-force traversal give the same image; rays = primaries + 16 per primary hit;
+    AO pixels are multiples of 1/16; a huge AO distance inside a closed box occludes every ray."""
+    sc = oracle.scene(scenes.cornell_box())
+    w = h = 48
+    c = cornell_consts(w, h, sky=False, fallback=0.0)
+    c.myAoDistance = 25.0
+    a, st = sc.render_ao(c, w, h, 0, 2)
+    b, _ = sc.render_ao(c, w, h, 0, 2, brute=True)
+    assert np.array_equal(a, b)
+    assert st["rays"] == st["samples"] + 16 * st["shaded_hits"]
+    assert st["shaded_hits"] + st["sky_misses"] == st["samples"]
+    assert np.all(np.abs(a[..., 0] * 16 - np.round(a[..., 0] * 16)) < 1e-5)
+    assert np.array_equal(a[..., 0], a[..., 1]) and np.array_equal(a[..., 0], a[..., 2]) and not a[..., 3].any()
+    c.myAoDistance = 1e-3                      # shorter than TMin 0.01: nothing can be hit -> ao = 1 on every hit pixel
+    a0, st0 = sc.render_ao(c, w, h, 0, 1)
+    hit = sc.primary_hits(c, w, h, 0)["prim"] != api.PT_MISS
+    assert np.all(a0[hit][:, 0] == 1.0) and not a0[~hit].any()
