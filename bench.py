@@ -44,11 +44,12 @@ def make_workload(name):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
-    ap.add_argument("--spp-per-step", type=int, default=4)
+    ap.add_argument("--spp-per-step", type=int, default=16,
+                    help="samples per pixel rendered by one step (one pt_render call = one wavefront batch)")
     ap.add_argument("--depth", type=int, default=-1, help="myMaxRecursionDepth (default: the workload's)")
     ap.add_argument("--workload", default="atrium", choices=["atrium", "street", "courtyard", "cornell"])
     ap.add_argument("--sky-mode", type=int, default=0, choices=[0, 1],

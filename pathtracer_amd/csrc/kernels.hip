@@ -331,8 +331,7 @@ __global__ void __launch_bounds__(PT_SHADE_THREADS) k_shade(PtRtConsts c, Device
         // ---- ClosestHit: PathTracing.hlsl:16-38, loaders Common.hlsl:75-127 ----
         const uint4 pd = sc.prim_data[prim];                 // LoadTriangleIndices + InstanceID()
         const uint32_t instanceId = pd.w;
-        const uint32_t materialIndex = sc.instance_material[instanceId];   // LoadInstanceData
-        const float4 mat = sc.materials[materialIndex];      // LoadMaterialData
+        const float4 mat = sc.instance_mat4[instanceId];     // LoadInstanceData + LoadMaterialData, pre-resolved per instance
         const float4 n0 = sc.vertex_normal[pd.x], n1 = sc.vertex_normal[pd.y], n2 = sc.vertex_normal[pd.z];
         const float bu = hr.y, bv = hr.z;                    // attrib.bary (DXR meaning, Q5)
         const float baryZ = 1.0f - (bu + bv);
@@ -345,7 +344,6 @@ __global__ void __launch_bounds__(PT_SHADE_THREADS) k_shade(PtRtConsts c, Device
 
         // ---- RayGen loop body: PathTracing.hlsl:83-127 ----
         float4 Ts = st_T[pid];
-        float4 Ls = st_L[pid];
         v3 transmission = mk3(Ts.x, Ts.y, Ts.z);
         Rng rng;
         const uint32_t pix = pid % wh;
@@ -376,8 +374,11 @@ __global__ void __launch_bounds__(PT_SHADE_THREADS) k_shade(PtRtConsts c, Device
           newDir = GetCosineWeightedHemisphereDirection(u, hitNormal);
         }
         const v3 add = transmission * emission;   // :108 — after the throughput update (Q3)
-        Ls.x += add.x; Ls.y += add.y; Ls.z += add.z;
-        st_L[pid] = Ls;
+        if (!(add.x == 0.0f && add.y == 0.0f && add.z == 0.0f)) {   // L + 0 == L: skip the RMW (a NaN term still lands, Q7)
+          float4 Ls = st_L[pid];
+          Ls.x += add.x; Ls.y += add.y; Ls.z += add.z;
+          st_L[pid] = Ls;
+        }
         if (!last_bounce) {
           st_T[pid] = make_float4(transmission.x, transmission.y, transmission.z, __uint_as_float(rng.w));
           newOrigin = hitPos;   // :126

@@ -347,7 +347,7 @@ int pt_scene_create(pt_ctx* ctx, const PtMeshDesc* meshes, uint32_t num_meshes, 
   ctx->ds = DeviceScene();
 
   uint4 *d_nodes, *d_tris, *d_prim;
-  float4 *d_vn, *d_mat;
+  float4 *d_vn, *d_mat, *d_imat;
   float2* d_uv;
   uint32_t* d_im;
   if ((rc = dev_alloc(ctx, &d_nodes, bvh.nodes.size() * 5, &ctx->scene_allocs))) return rc;
@@ -357,6 +357,11 @@ int pt_scene_create(pt_ctx* ctx, const PtMeshDesc* meshes, uint32_t num_meshes, 
   if ((rc = dev_alloc(ctx, &d_uv, (size_t)fs.num_vertices(), &ctx->scene_allocs))) return rc;
   if ((rc = dev_alloc(ctx, &d_im, fs.instance_material.size(), &ctx->scene_allocs))) return rc;
   if ((rc = dev_alloc(ctx, &d_mat, (size_t)num_materials, &ctx->scene_allocs))) return rc;
+  if ((rc = dev_alloc(ctx, &d_imat, fs.instance_material.size(), &ctx->scene_allocs))) return rc;
+  // LoadInstanceData + LoadMaterialData (Common.hlsl:75-100) resolved once per instance: one gather per hit, not two
+  std::vector<float> inst_mat(fs.instance_material.size() * 4);
+  for (size_t i = 0; i < fs.instance_material.size(); ++i)
+    memcpy(&inst_mat[4 * i], &fs.materials[4 * (size_t)fs.instance_material[i]], 16);
   auto up = [&](void* dst, const void* src, size_t bytes) -> hipError_t {
     return bytes ? hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice) : hipSuccess;
   };
@@ -367,6 +372,7 @@ int pt_scene_create(pt_ctx* ctx, const PtMeshDesc* meshes, uint32_t num_meshes, 
   PT_HIP(up(d_uv, fs.vertex_uv.data(), fs.vertex_uv.size() * 4));
   PT_HIP(up(d_im, fs.instance_material.data(), fs.instance_material.size() * 4));
   PT_HIP(up(d_mat, fs.materials.data(), fs.materials.size() * 4));
+  PT_HIP(up(d_imat, inst_mat.data(), inst_mat.size() * 4));
 
   ctx->ds.nodes = d_nodes;
   ctx->ds.tris = d_tris;
@@ -375,6 +381,7 @@ int pt_scene_create(pt_ctx* ctx, const PtMeshDesc* meshes, uint32_t num_meshes, 
   ctx->ds.vertex_uv = d_uv;
   ctx->ds.instance_material = d_im;
   ctx->ds.materials = d_mat;
+  ctx->ds.instance_mat4 = d_imat;
   ctx->ds.stack_entries = 2 * bvh.max_depth + 2;   // <=1 sibling group + <=1 postponed triangle group per level
   if (bvh.max_depth > 62)
     return ctx->fail(PT_ERR_UNSUPPORTED, "BVH deeper than the traversal stack supports (" + std::to_string(bvh.max_depth) + " levels)");
@@ -522,7 +529,10 @@ int pt_render(pt_ctx* ctx, const PtRtConsts* consts, uint32_t width, uint32_t he
   if ((uint64_t)first_sample + num_samples > 0xFFFFFFFFull) return ctx->fail(PT_ERR_INVALID_ARG, "sample index overflows 32 bits");
 
   const uint64_t wh = (uint64_t)width * height;
-  uint64_t spb = ctx->samples_per_batch > 0 ? (uint64_t)ctx->samples_per_batch : std::max<uint64_t>(1, (1ull << 23) / wh);
+  // Samples per wavefront batch. Every kernel of a batch ends with a drain of ~0.1 ms (the last waves of the persistent
+  // extend kernel finish their rays at memory latency, with nothing left to hide it), so batches are made large:
+  // 2^25 paths (5 GB of queues and path state) unless the caller asks otherwise.
+  uint64_t spb = ctx->samples_per_batch > 0 ? (uint64_t)ctx->samples_per_batch : std::max<uint64_t>(1, (1ull << 25) / wh);
   spb = std::min<uint64_t>(spb, num_samples);
   spb = std::min<uint64_t>(spb, std::max<uint64_t>(1, ((1ull << 31) - 1) / wh));
   if ((rc = ensure_wavefront(ctx, wh * spb)) != PT_OK) return rc;
