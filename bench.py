@@ -178,9 +178,21 @@ def main():
         ctx.set_option(api.PT_OPT_TIME_KERNELS, 0)
         ext_s = se.extend_ms * 1e-3
         achieved = bytes_per_ray * se.rays / max(ext_s, 1e-12) / 1e9
+        # (3) measured memory-side traffic of the same kernel: PMC counters cannot be read from inside this process, so the
+        #     figure comes from the committed rocprofv3 --pmc passes of this command (tools/prof_pmc.sh ->
+        #     tools/pmc_traffic.py -> profiles/r01/pmc_traffic.json), matched on workload, size and batch; null otherwise.
+        traffic, traffic_note = None, "no PMC profile committed for this workload/size"
+        try:
+            with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01", "pmc_traffic.json")) as f:
+                for e in json.load(f):
+                    if (e["workload"], e["width"], e["height"], e["spp_per_step"], e["depth"]) == (args.workload, W, H, SPP, depth):
+                        traffic = e["extend_bytes_per_launch"]
+                        traffic_note = e["note"]
+        except (OSError, ValueError, KeyError):
+            pass
         roofline = {
             "bound": "hbm", "kernel": "k_extend", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+            "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_note": traffic_note,
             "nodes_per_ray": round(nodes_per_ray, 3), "tris_per_ray": round(tris_per_ray, 3),
             "shipped_schedule": {"nodes_per_ray": round(ship.nodes_visited / max(1, ship.rays), 3),
                                  "tris_per_ray": round(ship.tris_tested / max(1, ship.rays), 3),

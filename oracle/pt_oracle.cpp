@@ -70,6 +70,12 @@ static inline void ClosestHit(const Scene& S, const PtRtConsts& c, const PtHit& 
   if (instanceId == c.myLightInstanceId) payload.myEmission = ld3(c.myLightEmission);
 }
 
+// Russian roulette (extension; BASELINE config C5). The reference only carries a commented-out sketch
+// (PathTracing.hlsl:110-124) that divides by the termination probability and "results in fireflies"; what is
+// implemented, here and in the HIP shade kernel, is the unbiased form at the same place in the loop and with the same
+// minBounces = 3: survive with probability q = clamp(luminance(transmission), 0.05, 1), then transmission /= q.
+static int g_russian_roulette = 0;
+
 struct SampleStats { uint64_t rays = 0, hits = 0, sky = 0, nodes = 0, tris = 0; };
 
 // RayGen — PathTracing.hlsl:40-138, one sample of one pixel. Returns the (scrubbed) luminance and the texel to write.
@@ -133,6 +139,11 @@ static inline float3 RayGenSample(const Scene& S, const PtRtConsts& c, const uin
       dir = GetCosineWeightedHemisphereDirection(float2{u0, u1}, hitInfo.myHitNormal);
     }
     luminance += transmission * hitInfo.myEmission;
+    if (g_russian_roulette && bounceIdx > 3u) {
+      const float q = clampf(GetLuminance(transmission), 0.05f, 1.0f);
+      if (GetRand01(rngState) >= q) break;
+      transmission /= q;
+    }
     origin = hitInfo.myHitPos;
     tmin = 0.001f;
   }
@@ -430,6 +441,8 @@ void orc_render_ao(void* s, const PtRtConsts* c, const uint16_t* lut, uint32_t w
 #endif
   }
 }
+
+void orc_set_russian_roulette(int on) { g_russian_roulette = on ? 1 : 0; }
 
 int orc_num_threads(void) {
 #ifdef _OPENMP

@@ -75,7 +75,7 @@ void launch_ao_rays(const PtRtConsts& c, const DeviceScene& sc, const WavefrontB
 void launch_ao_count(const WavefrontBuffers& wb, const float4* ao_hits, uint64_t n_paths, const LaunchCfg& cfg, hipStream_t s);
 void launch_hit_flags(const float4* hits, uint64_t n, uint8_t* flags, hipStream_t s);
 void launch_shade(const PtRtConsts& c, const DeviceScene& sc, const WavefrontBuffers& wb, int bounce, uint32_t w, uint32_t h,
-                  uint32_t first_sample, uint64_t max_paths, const LaunchCfg& cfg, hipStream_t s);
+                  uint32_t first_sample, uint64_t max_paths, bool russian_roulette, const LaunchCfg& cfg, hipStream_t s);
 void launch_skyview_lut(const PtRtConsts& c, const uint2* tlut, float4* out, hipStream_t s);   // out: PT_SKYVIEW_TEXELS float4
 void launch_sky(const PtRtConsts& c, const uint2* lut, const float4* skyview, const WavefrontBuffers& wb, uint64_t max_paths, const LaunchCfg& cfg, hipStream_t s);
 void launch_resolve(const WavefrontBuffers& wb, float4* accum, uint32_t w, uint32_t h, uint32_t samples_in_batch, uint32_t num_bounces,

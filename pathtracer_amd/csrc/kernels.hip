@@ -294,7 +294,7 @@ __global__ void __launch_bounds__(PT_SHADE_THREADS) k_shade(PtRtConsts c, Device
                                                float4* __restrict__ ray_d_out, uint32_t* __restrict__ qid_out,
                                                float4* __restrict__ sky_o, float4* __restrict__ sky_d,
                                                uint32_t* __restrict__ counters, int bounce, uint32_t w, uint32_t h,
-                                               uint32_t first_sample) {
+                                               uint32_t first_sample, uint32_t russian_roulette) {
   const uint32_t n = counters[CTR_AT(CTR_QCOUNT0 + bounce)];
   __shared__ BlockAppendLds s_app;
   const uint32_t lane = threadIdx.x & 63u;
@@ -379,7 +379,15 @@ __global__ void __launch_bounds__(PT_SHADE_THREADS) k_shade(PtRtConsts c, Device
           Ls.x += add.x; Ls.y += add.y; Ls.z += add.z;
           st_L[pid] = Ls;
         }
-        if (!last_bounce) {
+        // Russian roulette (extension, PT_OPT_RUSSIAN_ROULETTE): the unbiased form of the sketch at PathTracing.hlsl:110-124,
+        // same place in the loop, same minBounces = 3: survive with probability q = clamp(lum(T), 0.05, 1), T /= q.
+        bool alive = true;
+        if (russian_roulette && bounce > 3) {
+          const float q = clampf(GetLuminance(transmission), 0.05f, 1.0f);
+          if (GetRand01(rng) >= q) alive = false;
+          else transmission = transmission / q;
+        }
+        if (!last_bounce && alive) {
           st_T[pid] = make_float4(transmission.x, transmission.y, transmission.z, __uint_as_float(rng.w));
           newOrigin = hitPos;   // :126
           want_ray = true;
@@ -686,7 +694,7 @@ void launch_extend(const DeviceScene& sc, const float4* ray_o, const float4* ray
 }
 
 void launch_shade(const PtRtConsts& c, const DeviceScene& sc, const WavefrontBuffers& wb, int bounce, uint32_t w, uint32_t h,
-                  uint32_t first_sample, uint64_t max_paths, const LaunchCfg& cfg, hipStream_t s) {
+                  uint32_t first_sample, uint64_t max_paths, bool russian_roulette, const LaunchCfg& cfg, hipStream_t s) {
   const int in = bounce & 1, out = in ^ 1;
   uint64_t g = (max_paths + PT_SHADE_THREADS - 1) / PT_SHADE_THREADS;
   const uint64_t cap = (uint64_t)cfg.num_cus * 2u;
@@ -694,7 +702,7 @@ void launch_shade(const PtRtConsts& c, const DeviceScene& sc, const WavefrontBuf
   if (g < 1) g = 1;
   hipLaunchKernelGGL(k_shade, dim3((unsigned)g), dim3(PT_SHADE_THREADS), 0, s, c, sc, wb.ray_o[in], wb.ray_d[in],
                      bounce == 0 ? (const uint32_t*)nullptr : wb.qid[in], wb.hits, wb.st_T, wb.st_L, wb.ray_o[out], wb.ray_d[out],
-                     wb.qid[out], wb.sky_o, wb.sky_d, wb.counters, bounce, w, h, first_sample);
+                     wb.qid[out], wb.sky_o, wb.sky_d, wb.counters, bounce, w, h, first_sample, russian_roulette ? 1u : 0u);
 }
 
 void launch_ao_primary(const PtRtConsts& c, const WavefrontBuffers& wb, uint64_t n_paths, const LaunchCfg& cfg, hipStream_t s) {

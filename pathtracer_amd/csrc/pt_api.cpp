@@ -60,6 +60,7 @@ struct pt_ctx {
   bool time_kernels = false;
   int64_t samples_per_batch = 0;
   int sky_mode = 0;
+  bool russian_roulette = false;
 
   // timing
   std::vector<std::pair<hipEvent_t, hipEvent_t>> extend_events, render_events, event_pool;
@@ -297,6 +298,7 @@ int pt_set_option(pt_ctx* ctx, int option, int64_t value) {
       if (value < 0 || value > 4096) return ctx->fail(PT_ERR_INVALID_ARG, "samples per batch must be 0..4096");
       ctx->samples_per_batch = value;
       return PT_OK;
+    case PT_OPT_RUSSIAN_ROULETTE: ctx->russian_roulette = value != 0; return PT_OK;
     case PT_OPT_SKY_MODE:
       if (value != 0 && value != 1) return ctx->fail(PT_ERR_UNSUPPORTED, "sky mode must be 0 (ray-march on every miss) or 1 (direction LUT)");
       ctx->sky_mode = (int)value;
@@ -553,7 +555,7 @@ int pt_render(pt_ctx* ctx, const PtRtConsts* consts, uint32_t width, uint32_t he
     for (uint32_t b = 0; b < bounces; ++b) {
       const int in = (int)(b & 1u);
       extend_one(ctx, ctx->wb.ray_o[in], ctx->wb.ray_d[in], 1, ctx->wb.hits, ctx->wb.counters + CTR_AT(CTR_QCOUNT0 + b), ctx->wb.counters + CTR_AT(CTR_WORK0 + b), (int)b);
-      launch_shade(*consts, ctx->ds, ctx->wb, (int)b, width, height, first_sample + done, paths, ctx->cfg, ctx->stream);
+      launch_shade(*consts, ctx->ds, ctx->wb, (int)b, width, height, first_sample + done, paths, ctx->russian_roulette, ctx->cfg, ctx->stream);
     }
     if (consts->mySampleSky) launch_sky(*consts, ctx->lut, use_skyview ? ctx->skyview : nullptr, ctx->wb, paths, ctx->cfg, ctx->stream);
     launch_resolve(ctx->wb, ctx->accum, width, height, k, bounces, ctx->stream);

@@ -59,6 +59,7 @@ def load():
     lib.orc_float_to_half.argtypes = [C.c_float]
     lib.orc_half_to_float.restype = C.c_float
     lib.orc_half_to_float.argtypes = [C.c_uint16]
+    lib.orc_set_russian_roulette.argtypes = [C.c_int]
     lib.orc_num_threads.restype = C.c_int
     lib.orc_set_num_threads.argtypes = [C.c_int]
     _lib = lib
@@ -165,6 +166,9 @@ class Oracle:
     def encode_unorm_rgba(self, c):
         a = np.array(c, dtype=np.float32)
         return self.lib.orc_encode_unorm_rgba(api.ptr(a))
+
+    def set_russian_roulette(self, on):
+        self.lib.orc_set_russian_roulette(int(bool(on)))
 
     def num_threads(self):
         return self.lib.orc_num_threads()

@@ -342,6 +342,42 @@ def oracle_all_samples_hit(osc, c, w, h, first, spp):
     return m
 
 
+# ---------------------------------------------------------------------------------------------- Russian roulette (extension)
+def test_russian_roulette_matches_oracle_and_is_unbiased(ctx, cornell, oracle):
+    """PT_OPT_RUSSIAN_ROULETTE: same rays, hits and image as the oracle's restatement (ray counts exact, image to the
+    float tolerance); fewer rays than without; and the converged image agrees with the roulette-free one."""
+    sc, osc = cornell
+    ctx.scene_create(sc)
+    w, h, spp = 64, 64, 8
+    c = cornell_consts(w, h, depth=12, sky=False, fallback=0.0)
+    res = {}
+    try:
+        for rr in (0, 1):
+            ctx.set_option(api.PT_OPT_RUSSIAN_ROULETTE, rr)
+            oracle.set_russian_roulette(rr)
+            ctx.accum_reset(w, h)
+            ctx.stats_reset()
+            ctx.render(c, w, h, 0, spp)
+            img = ctx.accum_read()
+            st = ctx.stats()
+            acc, ost, _ = osc.render(c, w, h, 0, spp)
+            assert (st.rays, st.shaded_hits, st.sky_misses) == (ost["rays"], ost["shaded_hits"], ost["sky_misses"]), rr
+            assert rel_mse(img, acc / spp) < 1e-6, rr
+            res[rr] = (st.rays, img)
+        assert res[1][0] < 0.9 * res[0][0]                 # the roulette removes long paths
+        # unbiasedness, at a sample count where Monte-Carlo noise is below the bound: compare image means
+        means = {}
+        for rr in (0, 1):
+            ctx.set_option(api.PT_OPT_RUSSIAN_ROULETTE, rr)
+            ctx.accum_reset(w, h)
+            ctx.render(c, w, h, 100, 512)
+            means[rr] = ctx.accum_read()[..., :3].mean()
+        assert abs(means[1] - means[0]) / means[0] < 0.02, means
+    finally:
+        ctx.set_option(api.PT_OPT_RUSSIAN_ROULETTE, 0)
+        oracle.set_russian_roulette(0)
+
+
 # ---------------------------------------------------------------------------------------------- sky mode 1 (extension)
 @pytest.mark.parametrize("sun_dir", [(0.0, 1.0, 0.0), (0.3, 0.8, 0.52), (-0.7, 0.12, 0.2), (0.2, 0.02, -0.9)])
 def test_sky_view_lut_tracks_marched_sky(ctx, oracle, sun_dir):
