@@ -83,6 +83,6 @@ void launch_resolve(const WavefrontBuffers& wb, float4* accum, uint32_t w, uint3
 void launch_set_count(uint32_t* counter, uint32_t value, hipStream_t s);
 void launch_debug_eval(int fn, const PtRtConsts& c, const uint2* lut, const float4* skyview, const float* in, uint64_t n, float* out, hipStream_t s);
 size_t extend_lds_bytes(uint32_t stack_entries);
-int extend_occupancy_blocks(uint32_t lds_entries_total);
+int extend_occupancy_blocks(uint32_t lds_entries_total, bool defer);
 
 }  // namespace pt

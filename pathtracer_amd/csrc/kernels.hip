@@ -662,9 +662,11 @@ void launch_generate(const PtRtConsts& c, const WavefrontBuffers& wb, uint32_t w
 
 size_t extend_lds_bytes(uint32_t lds_entries_total) { return (size_t)lds_entries_total * 64u * sizeof(uint2) * 4u; }
 
-int extend_occupancy_blocks(uint32_t stack_entries) {
+int extend_occupancy_blocks(uint32_t lds_entries_total, bool defer) {
   int nb = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_extend<false, false>, 256, extend_lds_bytes(stack_entries)) != hipSuccess || nb < 1) nb = 1;
+  const hipError_t e = defer ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_extend<false, true>, 256, extend_lds_bytes(lds_entries_total))
+                             : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_extend<false, false>, 256, extend_lds_bytes(lds_entries_total));
+  if (e != hipSuccess || nb < 1) nb = 1;
   return nb;
 }
 

@@ -187,6 +187,16 @@ int ensure_tmp(pt_ctx* ctx, uint64_t rays) {
   return PT_OK;
 }
 
+// Persistent grid of the extend kernel: CUs x resident blocks of the instantiation that will be launched.
+int extend_grid(pt_ctx* ctx) {
+  int per_cu = ctx->cfg.extend_blocks_per_cu;
+  if (per_cu <= 0) {
+    const uint32_t lds_entries = std::min(ctx->ds.stack_entries, ctx->cfg.lds_stack_entries) + ctx->cfg.defer_entries;
+    per_cu = std::max(1, std::min(8, extend_occupancy_blocks(lds_entries, ctx->cfg.defer_entries > 0)));
+  }
+  return ctx->cfg.num_cus * per_cu;
+}
+
 int ensure_ao(pt_ctx* ctx, uint64_t rays) {
   if (ctx->ao_capacity >= rays) return PT_OK;
   PT_HIP(hipStreamSynchronize(ctx->stream));
@@ -315,19 +325,19 @@ int pt_set_option(pt_ctx* ctx, int option, int64_t value) {
       if (value < 1 || value > 128) return ctx->fail(PT_ERR_INVALID_ARG, "LDS stack entries must be 1..128");
       ctx->cfg.lds_stack_entries = (uint32_t)value;
       if (ctx->has_scene)
-        ctx->cfg.extend_blocks = ctx->cfg.num_cus * (ctx->cfg.extend_blocks_per_cu > 0 ? ctx->cfg.extend_blocks_per_cu : std::max(1, std::min(8, extend_occupancy_blocks(std::min(ctx->ds.stack_entries, ctx->cfg.lds_stack_entries) + ctx->cfg.defer_entries))));
+        ctx->cfg.extend_blocks = extend_grid(ctx);
       return PT_OK;
     case PT_OPT_EXTEND_DEFER:
       if (value < 0 || value > 16) return ctx->fail(PT_ERR_INVALID_ARG, "deferred-triangle queue must be 0..16 entries");
       ctx->cfg.defer_entries = (uint32_t)value;
       if (ctx->has_scene)
-        ctx->cfg.extend_blocks = ctx->cfg.num_cus * (ctx->cfg.extend_blocks_per_cu > 0 ? ctx->cfg.extend_blocks_per_cu : std::max(1, std::min(8, extend_occupancy_blocks(std::min(ctx->ds.stack_entries, ctx->cfg.lds_stack_entries) + ctx->cfg.defer_entries))));
+        ctx->cfg.extend_blocks = extend_grid(ctx);
       return PT_OK;
     case PT_OPT_EXTEND_BLOCKS_PER_CU:
       if (value < 0 || value > 16) return ctx->fail(PT_ERR_INVALID_ARG, "blocks per CU must be 0..16");
       ctx->cfg.extend_blocks_per_cu = (int)value;
       if (ctx->has_scene)
-        ctx->cfg.extend_blocks = ctx->cfg.num_cus * (value > 0 ? (int)value : std::max(1, std::min(8, extend_occupancy_blocks(std::min(ctx->ds.stack_entries, ctx->cfg.lds_stack_entries) + ctx->cfg.defer_entries))));
+        ctx->cfg.extend_blocks = extend_grid(ctx);
       return PT_OK;
     default: return ctx->fail(PT_ERR_INVALID_ARG, "unknown option");
   }
@@ -394,7 +404,7 @@ int pt_scene_create(pt_ctx* ctx, const PtMeshDesc* meshes, uint32_t num_meshes, 
     if ((rc = dev_alloc(ctx, &d_spill, waves * ctx->ds.stack_entries * 64u, &ctx->scene_allocs))) return rc;
     ctx->ds.spill = d_spill;
   }
-  ctx->cfg.extend_blocks = ctx->cfg.num_cus * (ctx->cfg.extend_blocks_per_cu > 0 ? ctx->cfg.extend_blocks_per_cu : std::max(1, std::min(8, extend_occupancy_blocks(std::min(ctx->ds.stack_entries, ctx->cfg.lds_stack_entries) + ctx->cfg.defer_entries))));
+  ctx->cfg.extend_blocks = extend_grid(ctx);
 
   PtSceneInfo& in = ctx->info;
   in.num_triangles = fs.num_triangles();
