@@ -43,7 +43,9 @@ __device__ __forceinline__ uint32_t wave_append(uint32_t* counter, bool pred) {
 // Block-aggregated append into two queues at once: one returning atomic per queue per BLOCK iteration (a single
 // counter word sustains only ~90 returning atomics/us chip-wide, so per-wave appends would bound the kernel).
 // Must be reached by every thread of the block; `parity` alternates per call so one barrier pair suffices.
-#define PT_SHADE_THREADS 1024
+// 512 threads: two blocks are resident per CU (the kernel needs ~100 VGPRs), so one block's wait on its append
+// atomic is covered by the other; 1024 was 5 % slower, 256 doubles the atomics and loses the gain again.
+#define PT_SHADE_THREADS 512
 struct BlockAppendLds {
   uint32_t cnt[2][2][PT_SHADE_THREADS / 64];   // [parity][queue][wave] -> count, then exclusive prefix
   uint32_t base[2][2];                          // [parity][queue]
@@ -699,7 +701,7 @@ void launch_shade(const PtRtConsts& c, const DeviceScene& sc, const WavefrontBuf
                   uint32_t first_sample, uint64_t max_paths, bool russian_roulette, const LaunchCfg& cfg, hipStream_t s) {
   const int in = bounce & 1, out = in ^ 1;
   uint64_t g = (max_paths + PT_SHADE_THREADS - 1) / PT_SHADE_THREADS;
-  const uint64_t cap = (uint64_t)cfg.num_cus * 2u;
+  const uint64_t cap = (uint64_t)cfg.num_cus * 8u;
   if (g > cap) g = cap;
   if (g < 1) g = 1;
   hipLaunchKernelGGL(k_shade, dim3((unsigned)g), dim3(PT_SHADE_THREADS), 0, s, c, sc, wb.ray_o[in], wb.ray_d[in],
@@ -709,7 +711,7 @@ void launch_shade(const PtRtConsts& c, const DeviceScene& sc, const WavefrontBuf
 
 void launch_ao_primary(const PtRtConsts& c, const WavefrontBuffers& wb, uint64_t n_paths, const LaunchCfg& cfg, hipStream_t s) {
   uint64_t g = (n_paths + PT_SHADE_THREADS - 1) / PT_SHADE_THREADS;
-  const uint64_t cap = (uint64_t)cfg.num_cus * 2u;
+  const uint64_t cap = (uint64_t)cfg.num_cus * 8u;
   g = g > cap ? cap : (g < 1 ? 1 : g);
   hipLaunchKernelGGL(k_ao_primary, dim3((unsigned)g), dim3(PT_SHADE_THREADS), 0, s, c, wb.ray_o[0], wb.ray_d[0], wb.hits, wb.st_L, wb.qid[0],
                      wb.sky_o, wb.sky_d, wb.counters);
