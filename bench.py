@@ -54,6 +54,9 @@ def main():
     ap.add_argument("--workload", default="atrium", choices=["atrium", "street", "courtyard", "cornell"])
     ap.add_argument("--sky-mode", type=int, default=0, choices=[0, 1],
                     help="0 = ray-march the sky on every miss (reference semantics); 1 = direction LUT (relMSE ~1e-6)")
+    ap.add_argument("--pipeline", type=int, default=0, choices=[0, 1],
+                    help="1 = two pipeline lanes per batch (PT_OPT_PIPELINE): higher throughput, but extend launches then "
+                         "overlap other kernels and the per-launch durations of the roofline grow")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
@@ -109,6 +112,7 @@ def main():
     consts = pt.BuildRtConsts()
     ctx.set_option(api.PT_OPT_SAMPLES_PER_BATCH, SPP)
     ctx.set_option(api.PT_OPT_SKY_MODE, args.sky_mode)
+    ctx.set_option(api.PT_OPT_PIPELINE, args.pipeline)
 
     total_steps = WU + K
     # this rank's sample indices: a contiguous block of (WU+K)*SPP samples
@@ -243,7 +247,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": label, "width": W, "height": H, "max_recursion_depth": depth, "spp_per_step": SPP,
-                       "sky_mode": args.sky_mode,
+                       "sky_mode": args.sky_mode, "pipeline": args.pipeline,
                        "triangles": int(info.num_triangles), "bvh_nodes": int(info.num_bvh_nodes),
                        "bvh_mb": round(info.bvh_bytes / 1e6, 2), "bvh_build_ms": round(info.build_ms, 1),
                        "rays_per_sample": round(rays_all / max(samples_all, 1), 3),

@@ -194,9 +194,13 @@ enum {
   PT_OPT_EXTEND_BLOCKS_PER_CU = 7, /* tuning: persistent grid = CUs x this (0 = occupancy query) */
   PT_OPT_EXTEND_LDS_STACK = 8,     /* tuning: per-lane traversal-stack entries kept in LDS (rest spills to HBM) */
   PT_OPT_EXTEND_DEFER = 9,         /* tuning: 0 = postpone triangles on the stack; N>0 = park up to N groups per lane */
-  PT_OPT_RUSSIAN_ROULETTE = 10     /* 0/1 (default 0 = reference behaviour): unbiased Russian roulette after bounce 3 — survive with
+  PT_OPT_RUSSIAN_ROULETTE = 10,    /* 0/1 (default 0 = reference behaviour): unbiased Russian roulette after bounce 3 — survive with
                                       q = clamp(luminance(throughput), 0.05, 1), throughput /= q (extension; the reference only has
                                       a commented-out, biased sketch at PathTracing.hlsl:110-124) */
+  PT_OPT_PIPELINE = 11             /* 0/1 (default 0): split every batch of >= 2 samples into two halves that run on two streams (the
+                                      second one internal): one half's shade kernels and kernel drains run under the other half's
+                                      extend, +2..5 % throughput, results bit-identical; off by default because concurrent kernels
+                                      blur the per-kernel durations that profiles and the bench's roofline are built on */
 };
 
 /* ---- lifetime (replaces the RenderCore device + handle ownership, PathTracer.cpp:45-77,417-437) ---- */

@@ -37,6 +37,7 @@ PT_OPT_EXTEND_BLOCKS_PER_CU = 7
 PT_OPT_EXTEND_LDS_STACK = 8
 PT_OPT_EXTEND_DEFER = 9
 PT_OPT_RUSSIAN_ROULETTE = 10
+PT_OPT_PIPELINE = 11
 
 (PT_FN_RAND01, PT_FN_FRESNEL, PT_FN_SPEC_PROB, PT_FN_SAMPLE_PHONG, PT_FN_EVAL_PHONG, PT_FN_COS_HEMISPHERE,
  PT_FN_LAMBERT, PT_FN_SKY, PT_FN_PRIMARY_RAY, PT_FN_SKY_VIEW_LUT) = range(10)

@@ -255,7 +255,10 @@ void build_bvh8(const float* verts, uint32_t n, Bvh8& out, int num_threads) {
   const uint32_t nn = (uint32_t)n2.size();
 
   // ---- SAH-optimal collapse (dynamic programme over "up to i roots", i = 1..7) ----
-  const float Cnode = 1.0f, Cprim = 0.3f;
+  // SAH constants of the collapse: cost of one 8-wide node step vs one triangle test. PT_BVH_CPRIM overrides the
+  // triangle cost for tuning runs (tools/tune_bvh.sh).
+  float Cnode = 1.0f, Cprim = 0.3f;
+  if (const char* e = getenv("PT_BVH_CPRIM")) { const float v = (float)atof(e); if (v > 0.0f) Cprim = v; }
   std::vector<float> cost((size_t)nn * 7);
   std::vector<uint8_t> dec((size_t)nn * 7);
   std::vector<uint8_t> isplit(nn, 0);

@@ -47,6 +47,14 @@ struct pt_ctx {
   // wavefront state
   WavefrontBuffers wb;
   std::vector<void*> wb_allocs;
+  // second pipeline lane (PT_OPT_PIPELINE): its own wavefront state, traversal-stack spill region and stream, so the
+  // two halves of a batch run concurrently (one half's shade and kernel drains under the other half's extend)
+  WavefrontBuffers wb2;
+  std::vector<void*> wb2_allocs;
+  uint2* spill2 = nullptr;
+  hipStream_t stream2 = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  bool pipeline = false;
   float4* ao_o = nullptr;       // AO pipeline: 16 rays per pixel-sample (origin,tmin / dir,tmax / hit records)
   float4* ao_d = nullptr;
   float4* ao_hits = nullptr;
@@ -141,34 +149,46 @@ void collect_events(pt_ctx* ctx) {
   ctx->render_events.clear();
 }
 
-int ensure_wavefront(pt_ctx* ctx, uint64_t paths) {
-  if (ctx->wb.capacity >= paths && ctx->wb.counters) return PT_OK;
+int ensure_wavefront_for(pt_ctx* ctx, WavefrontBuffers& wb, std::vector<void*>& allocs, uint64_t paths) {
+  if (wb.capacity >= paths && wb.counters) return PT_OK;
   PT_HIP(hipStreamSynchronize(ctx->stream));
-  unsigned long long* stats = ctx->wb.stats;  // statistics survive a re-allocation
+  if (ctx->stream2) PT_HIP(hipStreamSynchronize(ctx->stream2));
+  unsigned long long* stats = wb.stats;  // statistics survive a re-allocation
   std::vector<void*> keep;
-  for (void* p : ctx->wb_allocs)
+  for (void* p : allocs)
     if (p == (void*)stats) keep.push_back(p); else (void)hipFree(p);
-  ctx->wb_allocs = keep;
-  ctx->wb = WavefrontBuffers();
-  ctx->wb.stats = stats;
+  allocs = keep;
+  wb = WavefrontBuffers();
+  wb.stats = stats;
   int rc;
   for (int k = 0; k < 2; ++k) {
-    if ((rc = dev_alloc(ctx, &ctx->wb.ray_o[k], paths, &ctx->wb_allocs))) return rc;
-    if ((rc = dev_alloc(ctx, &ctx->wb.ray_d[k], paths, &ctx->wb_allocs))) return rc;
-    if ((rc = dev_alloc(ctx, &ctx->wb.qid[k], paths, &ctx->wb_allocs))) return rc;
+    if ((rc = dev_alloc(ctx, &wb.ray_o[k], paths, &allocs))) return rc;
+    if ((rc = dev_alloc(ctx, &wb.ray_d[k], paths, &allocs))) return rc;
+    if ((rc = dev_alloc(ctx, &wb.qid[k], paths, &allocs))) return rc;
   }
-  if ((rc = dev_alloc(ctx, &ctx->wb.hits, paths, &ctx->wb_allocs))) return rc;
-  if ((rc = dev_alloc(ctx, &ctx->wb.st_T, paths, &ctx->wb_allocs))) return rc;
-  if ((rc = dev_alloc(ctx, &ctx->wb.st_L, paths, &ctx->wb_allocs))) return rc;
-  if ((rc = dev_alloc(ctx, &ctx->wb.sky_o, paths, &ctx->wb_allocs))) return rc;
-  if ((rc = dev_alloc(ctx, &ctx->wb.sky_d, paths, &ctx->wb_allocs))) return rc;
-  if ((rc = dev_alloc(ctx, &ctx->wb.counters, (size_t)CTR_WORDS, &ctx->wb_allocs))) return rc;
-  if (!ctx->wb.stats) {
-    if ((rc = dev_alloc(ctx, &ctx->wb.stats, (size_t)ST_WORDS, &ctx->wb_allocs))) return rc;
-    PT_HIP(hipMemsetAsync(ctx->wb.stats, 0, ST_WORDS * sizeof(unsigned long long), ctx->stream));
+  if ((rc = dev_alloc(ctx, &wb.hits, paths, &allocs))) return rc;
+  if ((rc = dev_alloc(ctx, &wb.st_T, paths, &allocs))) return rc;
+  if ((rc = dev_alloc(ctx, &wb.st_L, paths, &allocs))) return rc;
+  if ((rc = dev_alloc(ctx, &wb.sky_o, paths, &allocs))) return rc;
+  if ((rc = dev_alloc(ctx, &wb.sky_d, paths, &allocs))) return rc;
+  if ((rc = dev_alloc(ctx, &wb.counters, (size_t)CTR_WORDS, &allocs))) return rc;
+  if (!wb.stats) {
+    if ((rc = dev_alloc(ctx, &wb.stats, (size_t)ST_WORDS, &allocs))) return rc;
+    PT_HIP(hipMemsetAsync(wb.stats, 0, ST_WORDS * sizeof(unsigned long long), ctx->stream));
   }
-  ctx->wb.capacity = paths;
+  wb.capacity = paths;
   return PT_OK;
+}
+
+int ensure_wavefront(pt_ctx* ctx, uint64_t paths) { return ensure_wavefront_for(ctx, ctx->wb, ctx->wb_allocs, paths); }
+
+int ensure_lane2(pt_ctx* ctx, uint64_t paths) {
+  if (!ctx->stream2) {
+    PT_HIP(hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
+    PT_HIP(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+    PT_HIP(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+  }
+  return ensure_wavefront_for(ctx, ctx->wb2, ctx->wb2_allocs, paths);
 }
 
 int ensure_tmp(pt_ctx* ctx, uint64_t rays) {
@@ -220,16 +240,23 @@ int check_consts(pt_ctx* ctx, const PtRtConsts* c, bool need_sky) {
 }
 
 void extend_one(pt_ctx* ctx, const float4* ro, const float4* rd, uint32_t stride, float4* hits, const uint32_t* count, uint32_t* cursor, int bounce = 0,
-                bool any_hit = false) {
+                bool any_hit = false, int lane = 0) {
+  const hipStream_t st = lane ? ctx->stream2 : ctx->stream;
   std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
   if (ctx->time_kernels) {
     ev = get_event_pair(ctx);
-    (void)hipEventRecord(ev.first, ctx->stream);
+    (void)hipEventRecord(ev.first, st);
   }
-  launch_extend(ctx->ds, ro, rd, stride, hits, count, cursor, ctx->wb.stats, ctx->count_traversal, any_hit, ctx->cfg, ctx->stream);
+  if (lane) {
+    DeviceScene ds2 = ctx->ds;
+    ds2.spill = ctx->spill2;
+    launch_extend(ds2, ro, rd, stride, hits, count, cursor, ctx->wb2.stats, ctx->count_traversal, any_hit, ctx->cfg, st);
+  } else {
+    launch_extend(ctx->ds, ro, rd, stride, hits, count, cursor, ctx->wb.stats, ctx->count_traversal, any_hit, ctx->cfg, st);
+  }
   ctx->extend_launches++;
   if (ctx->time_kernels) {
-    (void)hipEventRecord(ev.second, ctx->stream);
+    (void)hipEventRecord(ev.second, st);
     ctx->extend_events.push_back(ev);
     ctx->extend_event_bounce.push_back(bounce);
   }
@@ -273,7 +300,12 @@ int pt_destroy(pt_ctx* ctx) {
   collect_events(ctx);
   for (auto& p : ctx->event_pool) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
   free_list(ctx->scene_allocs);
+  if (ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);
   free_list(ctx->wb_allocs);
+  free_list(ctx->wb2_allocs);
+  if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+  if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
+  if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
   if (ctx->tmp_rays) (void)hipFree(ctx->tmp_rays);
   if (ctx->tmp_hits) (void)hipFree(ctx->tmp_hits);
   if (ctx->lut) (void)hipFree(ctx->lut);
@@ -309,6 +341,7 @@ int pt_set_option(pt_ctx* ctx, int option, int64_t value) {
       ctx->samples_per_batch = value;
       return PT_OK;
     case PT_OPT_RUSSIAN_ROULETTE: ctx->russian_roulette = value != 0; return PT_OK;
+    case PT_OPT_PIPELINE: ctx->pipeline = value != 0; return PT_OK;
     case PT_OPT_SKY_MODE:
       if (value != 0 && value != 1) return ctx->fail(PT_ERR_UNSUPPORTED, "sky mode must be 0 (ray-march on every miss) or 1 (direction LUT)");
       ctx->sky_mode = (int)value;
@@ -403,6 +436,7 @@ int pt_scene_create(pt_ctx* ctx, const PtMeshDesc* meshes, uint32_t num_meshes, 
     uint2* d_spill = nullptr;
     if ((rc = dev_alloc(ctx, &d_spill, waves * ctx->ds.stack_entries * 64u, &ctx->scene_allocs))) return rc;
     ctx->ds.spill = d_spill;
+    if ((rc = dev_alloc(ctx, &ctx->spill2, waves * ctx->ds.stack_entries * 64u, &ctx->scene_allocs))) return rc;   // pipeline lane 2
   }
   ctx->cfg.extend_blocks = extend_grid(ctx);
 
@@ -547,7 +581,13 @@ int pt_render(pt_ctx* ctx, const PtRtConsts* consts, uint32_t width, uint32_t he
   uint64_t spb = ctx->samples_per_batch > 0 ? (uint64_t)ctx->samples_per_batch : std::max<uint64_t>(1, (1ull << 25) / wh);
   spb = std::min<uint64_t>(spb, num_samples);
   spb = std::min<uint64_t>(spb, std::max<uint64_t>(1, ((1ull << 31) - 1) / wh));
-  if ((rc = ensure_wavefront(ctx, wh * spb)) != PT_OK) return rc;
+  // Two pipeline lanes: a batch of k >= 2 samples is split into a lower and an upper half that run on two streams with
+  // their own queues, so one half's shade kernels and kernel drains run under the other half's extend. The halves are
+  // resolved in sample order on the ctx stream, so the target is bit-identical to the single-lane result.
+  const bool two_lanes = ctx->pipeline && spb >= 2;
+  const uint64_t spb_a = two_lanes ? (spb + 1) / 2 : spb;
+  if ((rc = ensure_wavefront(ctx, wh * spb_a)) != PT_OK) return rc;
+  if (two_lanes && (rc = ensure_lane2(ctx, wh * (spb - spb_a))) != PT_OK) return rc;
 
   std::pair<hipEvent_t, hipEvent_t> rev{nullptr, nullptr};
   if (ctx->time_kernels) {
@@ -559,16 +599,34 @@ int pt_render(pt_ctx* ctx, const PtRtConsts* consts, uint32_t width, uint32_t he
   if (use_skyview) launch_skyview_lut(*consts, ctx->lut, ctx->skyview, ctx->stream);   // 64 Ki texels, a few microseconds
   for (uint32_t done = 0; done < num_samples;) {
     const uint32_t k = (uint32_t)std::min<uint64_t>(spb, num_samples - done);
-    const uint64_t paths = wh * k;
-    PT_HIP(hipMemsetAsync(ctx->wb.counters, 0, CTR_WORDS * sizeof(uint32_t), ctx->stream));
-    launch_generate(*consts, ctx->wb, width, height, first_sample + done, k, ctx->stream);
+    const uint32_t k_lane[2] = {two_lanes && k >= 2 ? (k + 1) / 2 : k, two_lanes && k >= 2 ? k / 2 : 0};
+    const uint32_t first_lane[2] = {first_sample + done, first_sample + done + k_lane[0]};
+    const int n_lanes = k_lane[1] ? 2 : 1;
+    WavefrontBuffers* wbs[2] = {&ctx->wb, &ctx->wb2};
+    const hipStream_t streams[2] = {ctx->stream, ctx->stream2};
+    if (n_lanes == 2) {   // lane 1 starts after everything queued on the ctx stream so far (previous resolve included)
+      PT_HIP(hipEventRecord(ctx->ev_fork, ctx->stream));
+      PT_HIP(hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
+    }
+    for (int l = 0; l < n_lanes; ++l) {
+      PT_HIP(hipMemsetAsync(wbs[l]->counters, 0, CTR_WORDS * sizeof(uint32_t), streams[l]));
+      launch_generate(*consts, *wbs[l], width, height, first_lane[l], k_lane[l], streams[l]);
+    }
     for (uint32_t b = 0; b < bounces; ++b) {
       const int in = (int)(b & 1u);
-      extend_one(ctx, ctx->wb.ray_o[in], ctx->wb.ray_d[in], 1, ctx->wb.hits, ctx->wb.counters + CTR_AT(CTR_QCOUNT0 + b), ctx->wb.counters + CTR_AT(CTR_WORK0 + b), (int)b);
-      launch_shade(*consts, ctx->ds, ctx->wb, (int)b, width, height, first_sample + done, paths, ctx->russian_roulette, ctx->cfg, ctx->stream);
+      for (int l = 0; l < n_lanes; ++l) {
+        WavefrontBuffers& wb = *wbs[l];
+        extend_one(ctx, wb.ray_o[in], wb.ray_d[in], 1, wb.hits, wb.counters + CTR_AT(CTR_QCOUNT0 + b), wb.counters + CTR_AT(CTR_WORK0 + b), (int)b, false, l);
+        launch_shade(*consts, ctx->ds, wb, (int)b, width, height, first_lane[l], wh * k_lane[l], ctx->russian_roulette, ctx->cfg, streams[l]);
+      }
     }
-    if (consts->mySampleSky) launch_sky(*consts, ctx->lut, use_skyview ? ctx->skyview : nullptr, ctx->wb, paths, ctx->cfg, ctx->stream);
-    launch_resolve(ctx->wb, ctx->accum, width, height, k, bounces, ctx->stream);
+    for (int l = 0; l < n_lanes; ++l)
+      if (consts->mySampleSky) launch_sky(*consts, ctx->lut, use_skyview ? ctx->skyview : nullptr, *wbs[l], wh * k_lane[l], ctx->cfg, streams[l]);
+    if (n_lanes == 2) {
+      PT_HIP(hipEventRecord(ctx->ev_join, ctx->stream2));
+      PT_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+    }
+    for (int l = 0; l < n_lanes; ++l) launch_resolve(*wbs[l], ctx->accum, width, height, k_lane[l], bounces, ctx->stream);   // sample order
     done += k;
   }
   PT_HIP(hipGetLastError());
@@ -747,17 +805,18 @@ int pt_stats_get(pt_ctx* ctx, PtStats* out) {
   memset(out, 0, sizeof(*out));
   PT_HIP(hipStreamSynchronize(ctx->stream));
   collect_events(ctx);
-  if (ctx->wb.stats) {
+  for (const WavefrontBuffers* wb : {&ctx->wb, &ctx->wb2}) {   // both pipeline lanes
+    if (!wb->stats) continue;
     unsigned long long h[ST_WORDS];
-    PT_HIP(hipMemcpy(h, ctx->wb.stats, sizeof(h), hipMemcpyDeviceToHost));
-    out->samples = h[ST_SAMPLES];
-    out->rays = h[ST_RAYS];
-    out->shaded_hits = h[ST_SHADED];
-    out->sky_misses = h[ST_SKY];
-    out->nodes_visited = h[ST_NODES];
-    out->tris_tested = h[ST_TRIS];
-    out->node_wave_steps = h[ST_NODE_WAVE_STEPS];
-    out->tri_wave_steps = h[ST_TRI_WAVE_STEPS];
+    PT_HIP(hipMemcpy(h, wb->stats, sizeof(h), hipMemcpyDeviceToHost));
+    out->samples += h[ST_SAMPLES];
+    out->rays += h[ST_RAYS];
+    out->shaded_hits += h[ST_SHADED];
+    out->sky_misses += h[ST_SKY];
+    out->nodes_visited += h[ST_NODES];
+    out->tris_tested += h[ST_TRIS];
+    out->node_wave_steps += h[ST_NODE_WAVE_STEPS];
+    out->tri_wave_steps += h[ST_TRI_WAVE_STEPS];
     for (int b = 0; b < 64; ++b) out->rays_bounce[std::min(15, b)] += h[ST_RAYS_BOUNCE0 + b];
   }
   for (int b = 0; b < 16; ++b) out->extend_ms_bounce[b] = ctx->extend_ms_bounce[b];
@@ -776,6 +835,7 @@ int pt_stats_reset(pt_ctx* ctx) {
   ctx->extend_launches = 0;
   for (int b = 0; b < 16; ++b) ctx->extend_ms_bounce[b] = 0.0;
   if (ctx->wb.stats) PT_HIP(hipMemset(ctx->wb.stats, 0, ST_WORDS * sizeof(unsigned long long)));
+  if (ctx->wb2.stats) PT_HIP(hipMemset(ctx->wb2.stats, 0, ST_WORDS * sizeof(unsigned long long)));
   return PT_OK;
 }
 

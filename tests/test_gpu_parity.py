@@ -342,6 +342,35 @@ def oracle_all_samples_hit(osc, c, w, h, first, spp):
     return m
 
 
+# ---------------------------------------------------------------------------------------------- two pipeline lanes
+def test_pipeline_lanes_are_bit_identical_to_single_lane(ctx, oracle):
+    """PT_OPT_PIPELINE splits a batch over two streams; the halves are resolved in sample order, so the target and
+    the counters must not change by a bit (odd sample counts and several batches included)."""
+    sc = scenes.atrium(1)
+    ctx.scene_create(sc)
+    ctx.sky_set(oracle.earth_atmosphere())
+    w, h = 200, 120
+    c = lookat_consts(w, h, scenes.ATRIUM_CAM)
+    out = {}
+    try:
+        for pipe in (0, 1):
+            ctx.set_option(api.PT_OPT_PIPELINE, pipe)
+            ctx.set_option(api.PT_OPT_SAMPLES_PER_BATCH, 5)
+            ctx.accum_reset(w, h)
+            ctx.stats_reset()
+            ctx.render(c, w, h, 3, 13)          # batches of 5, 5, 3 -> lanes of 3+2, 3+2, 2+1
+            ctx.render(c, w, h, 16, 1)          # a single sample cannot be split
+            img, n = ctx.accum_read_sum()
+            st = ctx.stats()
+            out[pipe] = (img, n, st.rays, st.shaded_hits, st.sky_misses, st.samples, list(st.rays_bounce))
+    finally:
+        ctx.set_option(api.PT_OPT_PIPELINE, 0)
+        ctx.set_option(api.PT_OPT_SAMPLES_PER_BATCH, 0)
+    assert out[0][1:] == out[1][1:]
+    assert np.array_equal(out[0][0], out[1][0])
+    assert out[0][1] == 14
+
+
 # ---------------------------------------------------------------------------------------------- Russian roulette (extension)
 def test_russian_roulette_matches_oracle_and_is_unbiased(ctx, cornell, oracle):
     """PT_OPT_RUSSIAN_ROULETTE: same rays, hits and image as the oracle's restatement (ray counts exact, image to the

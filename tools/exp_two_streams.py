@@ -43,7 +43,7 @@ def run(pts, spp_each, blocks_per_cu=0):
     rays = sum(p.ctx.stats().rays for p in pts)
     return dt / K * 1e3, rays / dt / 1e6
 
-cfgs = [(1, 4), (1, 8), (1, 16), (2, 4), (2, 8), (3, 4), (4, 4), (4, 2)]
+cfgs = [(1, 16), (2, 8), (2, 16), (3, 8), (1, 32)]
 for nctx, spp in cfgs:
     pts = [make(spp) for _ in range(nctx)]
     ms, mr = run(pts, spp)
