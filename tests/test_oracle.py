@@ -228,3 +228,24 @@ def test_ao_pipeline_bvh_equals_brute_force_and_counts(oracle):
     a0, st0 = sc.render_ao(c, w, h, 0, 1)
     hit = sc.primary_hits(c, w, h, 0)["prim"] != api.PT_MISS
     assert np.all(a0[hit][:, 0] == 1.0) and not a0[~hit].any()
+
+
+def test_ao_and_russian_roulette_regression_pins(oracle):
+    """tests/golden/cornell_ao_64_4spp.* and cornell_rr_64_8spp_stats.json (tools/make_golden.py)."""
+    sc = oracle.scene(scenes.cornell_box())
+    c = cornell_consts(64, 64, sky=False, fallback=0.0)
+    c.myAoDistance = 25.0
+    acc, st = sc.render_ao(c, 64, 64, 0, 4)
+    assert np.array_equal(acc[..., 0], np.load(os.path.join(G, "cornell_ao_64_4spp.npy")))
+    pin = json.load(open(os.path.join(G, "cornell_ao_64_4spp_stats.json")))
+    assert {k: st[k] for k in pin} == pin
+    pin = json.load(open(os.path.join(G, "cornell_rr_64_8spp_stats.json")))
+    c = cornell_consts(64, 64, depth=12, sky=False, fallback=0.0)
+    try:
+        for on in (0, 1):
+            oracle.set_russian_roulette(on)
+            acc, st, _ = sc.render(c, 64, 64, 0, 8)
+            assert (st["rays"], st["shaded_hits"], st["sky_misses"]) == tuple(pin[str(on)][k] for k in ("rays", "shaded_hits", "sky_misses"))
+            assert abs(float(acc[..., :3].astype(np.float64).sum()) - pin[str(on)]["sum_rgb"]) <= 1e-6 * abs(pin[str(on)]["sum_rgb"])
+    finally:
+        oracle.set_russian_roulette(0)

@@ -75,4 +75,25 @@ for fn in range(1, api.PT_FN_COUNT if hasattr(api, "PT_FN_COUNT") else 9):
     tables[f"in_{fn}"] = x
     tables[f"out_{fn}"] = y
 np.savez_compressed(os.path.join(G, "function_tables.npz"), **tables)
+# ---- AO pipeline (Ao.hlsl): Cornell 64^2, 4 spp, sky off, AO distance 25: occluded-ray counts are integers ----
+c = cornell_consts(64, 64, sky=False, fallback=0.0)
+c.myAoDistance = 25.0
+acc, st = osc.render_ao(c, 64, 64, 0, 4)
+acc_b, _ = osc.render_ao(c, 64, 64, 0, 4, brute=True)
+assert np.array_equal(acc, acc_b)
+np.save(os.path.join(G, "cornell_ao_64_4spp.npy"), acc[..., 0].astype(np.float32))
+json.dump({k: int(v) for k, v in st.items() if k in ("rays", "shaded_hits", "sky_misses", "samples")},
+          open(os.path.join(G, "cornell_ao_64_4spp_stats.json"), "w"))
+
+# ---- Russian roulette (extension): Cornell 64^2, 8 spp, depth 12: ray counts with and without ----
+c = cornell_consts(64, 64, depth=12, sky=False, fallback=0.0)
+rr = {}
+for on in (0, 1):
+    orc.set_russian_roulette(on)
+    acc, st, _ = osc.render(c, 64, 64, 0, 8)
+    rr[str(on)] = {"rays": st["rays"], "shaded_hits": st["shaded_hits"], "sky_misses": st["sky_misses"],
+                   "sum_rgb": float(acc[..., :3].astype(np.float64).sum())}
+orc.set_russian_roulette(0)
+json.dump(rr, open(os.path.join(G, "cornell_rr_64_8spp_stats.json"), "w"), indent=1)
+
 print("golden fixtures written to", G, sorted(os.listdir(G)))
