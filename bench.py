@@ -54,6 +54,10 @@ def main():
     ap.add_argument("--workload", default="atrium", choices=["atrium", "street", "courtyard", "cornell"])
     ap.add_argument("--sky-mode", type=int, default=0, choices=[0, 1],
                     help="0 = ray-march the sky on every miss (reference semantics); 1 = direction LUT (relMSE ~1e-6)")
+    ap.add_argument("--material-ext", type=int, default=0, choices=[0, 1],
+                    help="1 = attach the GGX + procedural-albedo material extension (BASELINE C4/C5 'extension' variant; the "
+                         "reference's own materials are Lambert + Phong, the default)")
+    ap.add_argument("--russian-roulette", type=int, default=0, choices=[0, 1], help="PT_OPT_RUSSIAN_ROULETTE (C5 variant)")
     ap.add_argument("--pipeline", type=int, default=0, choices=[0, 1],
                     help="1 = two pipeline lanes per batch (PT_OPT_PIPELINE): higher throughput, but extend launches then "
                          "overlap other kernels and the per-launch durations of the roofline grow")
@@ -87,6 +91,10 @@ def main():
     scene, cam, depth, label = make_workload(args.workload)
     if args.depth >= 0:
         depth = args.depth
+    if args.material_ext:
+        from pathtracer_amd import scenes as _scn
+        scene = _scn.with_material_ext(scene)
+        label += ", GGX + procedural albedo (extension)"
 
     pt = PathTracer(local_rank, W, H)
     pt.myHalfResRender = False
@@ -113,6 +121,7 @@ def main():
     ctx.set_option(api.PT_OPT_SAMPLES_PER_BATCH, SPP)
     ctx.set_option(api.PT_OPT_SKY_MODE, args.sky_mode)
     ctx.set_option(api.PT_OPT_PIPELINE, args.pipeline)
+    ctx.set_option(api.PT_OPT_RUSSIAN_ROULETTE, args.russian_roulette)
 
     total_steps = WU + K
     # this rank's sample indices: a contiguous block of (WU+K)*SPP samples
@@ -216,6 +225,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from tests import oracle_lib
         orc = oracle_lib.load()
+        orc.set_russian_roulette(args.russian_roulette)   # the CPU leg runs the same variant of the workload
         oscene = orc.scene(scene)
         lut = orc.transmittance_lut(pt.mySky.myAtmosphereParams) if pt.mySampleSky else None
         # bounded sample of the same workload (same scene, camera, depth, sky): a short calibration pass at 1/4
@@ -248,6 +258,7 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": label, "width": W, "height": H, "max_recursion_depth": depth, "spp_per_step": SPP,
                        "sky_mode": args.sky_mode, "pipeline": args.pipeline,
+                       "material_ext": args.material_ext, "russian_roulette": args.russian_roulette,
                        "triangles": int(info.num_triangles), "bvh_nodes": int(info.num_bvh_nodes),
                        "bvh_mb": round(info.bvh_bytes / 1e6, 2), "bvh_build_ms": round(info.build_ms, 1),
                        "rays_per_sample": round(rays_all / max(samples_all, 1), 3),

@@ -213,6 +213,23 @@ int pt_set_stream(pt_ctx* ctx, void* hip_stream);
 int pt_synchronize(pt_ctx* ctx);
 int pt_set_option(pt_ctx* ctx, int option, int64_t value);
 
+/* Material extension for BASELINE configs C4/C5 — NOT in the reference, whose materials are untextured Lambert +
+ * modified Phong (PathTracing.hlsl:83-106, MaterialData at PathTracer.cpp:318-329). One record per material of the last
+ * pt_scene_create, same order. Materials with PT_MAT_GGX set are shaded with a GGX specular lobe (visible-normal
+ * sampling, separable Smith) + Lambert diffuse in the metallic/roughness parametrisation; albedo_pattern modulates the
+ * base colour by a procedural function of the interpolated uv (either material model). The definition is
+ * pathtracer_amd/csrc/ggx_device.h; oracle/ggx.h restates it. ext == NULL or num_materials == 0 removes the extension. */
+#define PT_MAT_GGX 1u
+typedef struct PtMaterialExt {
+  float roughness;          /* GGX alpha = max(roughness^2, 1e-3) */
+  float metallic;           /* F0 = lerp(0.04, base, metallic); diffuse = base * (1 - metallic) */
+  uint32_t albedo_pattern;  /* 0 = none, 1 = checker (1 / 0.35), 2 = smooth value noise in [0.35, 1) */
+  float pattern_scale;      /* uv multiplier */
+  uint32_t flags;           /* PT_MAT_GGX */
+  uint32_t reserved[3];
+} PtMaterialExt;
+int pt_scene_set_material_ext(pt_ctx* ctx, const PtMaterialExt* ext, uint32_t num_materials);
+
 /* ---- scene: replaces PathTracer::InitRtScene incl. the driver BLAS/TLAS build (PathTracer.cpp:171-339) ----
  * Flattens meshes x instances into world-space SoA triangle / vertex{normal,uv} / material buffers,
  * builds a binned-SAH BVH collapsed to an 8-wide compressed BVH on the host and uploads everything.
@@ -291,7 +308,10 @@ enum {
   PT_FN_PRIMARY_RAY = 8,       /* in: pixel2,res2 (4)      -> out: 6   origin3,dir3 GetPrimaryRay Common.hlsl:183-189 */
   PT_FN_SKY_VIEW_LUT = 9,      /* in: viewPos3,viewDir3 (6)-> out: 3   sky-mode-1 stand-in for PT_FN_SKY: bilinear fetch from the
                                   direction LUT built for consts->myCameraPos (extension; viewPos only feeds the march's domain tests) */
-  PT_FN_COUNT = 10
+  PT_FN_GGX_SAMPLE = 10,       /* in: base3,roughness,metallic,N3,V3,px,py,seed (14) -> out: alive,weight3,dir3,draws (8)
+                                  SampleGgxMaterial of the material extension (ggx_device.h), RNG = InitRNG(px,py,seed) */
+  PT_FN_ALBEDO_PATTERN = 11,   /* in: pattern,scale,u,v (4) -> out: 1   AlbedoPattern of the material extension */
+  PT_FN_COUNT = 12
 };
 
 #ifdef __cplusplus

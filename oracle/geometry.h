@@ -29,6 +29,7 @@ struct Scene {
   std::vector<float2> vertex_uv;         // VertexData.myUv
   std::vector<uint32_t> instance_material;  // InstanceData.myMaterialIndex (PathTracer.cpp:276-295)
   std::vector<PtMaterial> materials;     // MaterialData (PathTracer.cpp:318-329)
+  std::vector<PtMaterialExt> materials_ext;  // material extension (include/pt_api.h), empty = none; NOT in the reference
   // BVH2
   struct Node { float lo[3], hi[3]; uint32_t left, count; };  // count>0: leaf, left = first index into order[]
   std::vector<Node> nodes;

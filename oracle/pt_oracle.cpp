@@ -29,6 +29,7 @@
 #include "geometry.h"
 #include "shading.h"
 #include "sky.h"
+#include "ggx.h"
 
 using namespace orc;
 
@@ -44,6 +45,9 @@ static inline float3 ld3(const float* p) { return f3(p[0], p[1], p[2]); }
 struct HitInfo {  // PathTracing.hlsl:7-14
   float3 myHitPos, myHitNormal, myColor, myEmission;
   bool myHasHit;
+  // material extension (not in the reference): GGX flag and parameters of the hit's material
+  bool myGgx = false;
+  float myRoughness = 0.0f, myMetallic = 0.0f;
 };
 
 // ClosestHit — PathTracing.hlsl:16-38 (+ loaders Common.hlsl:75-127)
@@ -66,6 +70,20 @@ static inline void ClosestHit(const Scene& S, const PtRtConsts& c, const PtHit& 
   payload.myHitPos = rayOrigin + rayDir * h.t;
   payload.myColor = matColor;
   payload.myEmission = matEmission;
+  payload.myGgx = false;
+  if (!S.materials_ext.empty()) {   // extension: procedural albedo from the interpolated uv, GGX parameters
+    const PtMaterialExt& e = S.materials_ext[materialIndex];
+    if (e.albedo_pattern != 0u) {
+      float2 t0 = S.vertex_uv[idx[0]], t1 = S.vertex_uv[idx[1]], t2 = S.vertex_uv[idx[2]];
+      float2 uv;   // LoadInterpolatedVertexData weights (Common.hlsl:121-126), as for the normal
+      uv.x = h.u * t0.x + h.v * t1.x + baryZ * t2.x;
+      uv.y = h.u * t0.y + h.v * t1.y + baryZ * t2.y;
+      payload.myColor = payload.myColor * AlbedoPattern(e.albedo_pattern, e.pattern_scale, uv);
+    }
+    payload.myGgx = (e.flags & PT_MAT_GGX_BIT) != 0u;
+    payload.myRoughness = e.roughness;
+    payload.myMetallic = e.metallic;
+  }
   if (dot(payload.myHitNormal, -rayDir) < 0.0f) payload.myHitNormal = -payload.myHitNormal;
   if (instanceId == c.myLightInstanceId) payload.myEmission = ld3(c.myLightEmission);
 }
@@ -118,6 +136,12 @@ static inline float3 RayGenSample(const Scene& S, const PtRtConsts& c, const uin
     st.hits++;
     float specularStrength = 0.9f;
     float specularPower = c.myPhongSpecularPower;
+    if (hitInfo.myGgx) {   // material extension (ggx.h); a direction below the surface ends the path with no contribution
+      float3 nextDir;
+      if (!SampleGgxMaterial(hitInfo.myColor, hitInfo.myRoughness, hitInfo.myMetallic, hitInfo.myHitNormal, -dir, rngState, transmission, nextDir))
+        break;
+      dir = nextDir;
+    } else {
     float fresnel = GetFresnelSchlick(hitInfo.myHitNormal, -dir);
     float specRayProbability = EstimateSpecularRayProbability(specularStrength, hitInfo.myColor, fresnel);
     if (GetRand01(rngState) < specRayProbability) {
@@ -137,6 +161,7 @@ static inline float3 RayGenSample(const Scene& S, const PtRtConsts& c, const uin
       float u0 = GetRand01(rngState);
       float u1 = GetRand01(rngState);
       dir = GetCosineWeightedHemisphereDirection(float2{u0, u1}, hitInfo.myHitNormal);
+    }
     }
     luminance += transmission * hitInfo.myEmission;
     if (g_russian_roulette && bounceIdx > 3u) {
@@ -289,6 +314,18 @@ int orc_eval(int fn, const PtRtConsts* c, const uint16_t* lut, const float* in, 
                       ld3(c->myYAxis), ld3(c->myCameraPos), o, d);
         out[6 * i] = o.x; out[6 * i + 1] = o.y; out[6 * i + 2] = o.z; out[6 * i + 3] = d.x; out[6 * i + 4] = d.y; out[6 * i + 5] = d.z;
       } break;
+      case PT_FN_GGX_SAMPLE: {
+        const float* r = in + 14 * i;
+        uint4 rng = InitRNG((uint32_t)r[11], (uint32_t)r[12], (uint32_t)r[13]);
+        float3 T = f3(1.0f), d = f3(0.0f);
+        const bool alive = SampleGgxMaterial(ld3(r), r[3], r[4], ld3(r + 5), ld3(r + 8), rng, T, d);
+        float* o = out + 8 * i;
+        o[0] = alive ? 1.0f : 0.0f; o[1] = T.x; o[2] = T.y; o[3] = T.z; o[4] = d.x; o[5] = d.y; o[6] = d.z; o[7] = (float)rng.w;
+      } break;
+      case PT_FN_ALBEDO_PATTERN: {
+        const float* r = in + 4 * i;
+        out[i] = AlbedoPattern((uint32_t)r[0], r[1], float2{r[2], r[3]});
+      } break;
       default: return 1;
     }
   }
@@ -306,6 +343,14 @@ void* orc_scene_create(const PtMeshDesc* meshes, uint32_t nm, const PtInstanceDe
   return S;
 }
 void orc_scene_destroy(void* s) { delete (Scene*)s; }
+// material extension (include/pt_api.h PtMaterialExt): one record per material, or n == 0 to remove
+int orc_scene_set_material_ext(void* s, const PtMaterialExt* ext, uint32_t n) {
+  Scene& S = *(Scene*)s;
+  if (!ext || n == 0) { S.materials_ext.clear(); return 0; }
+  if (n != S.materials.size()) return 1;
+  S.materials_ext.assign(ext, ext + n);
+  return 0;
+}
 uint32_t orc_scene_num_triangles(void* s) { return (uint32_t)((Scene*)s)->tris.size(); }
 // world-space triangle i as 9 floats + its instance id (so tests can check the product's flattening)
 void orc_scene_triangle(void* s, uint32_t i, float out9[9], uint32_t* instance) {

@@ -40,9 +40,9 @@ PT_OPT_RUSSIAN_ROULETTE = 10
 PT_OPT_PIPELINE = 11
 
 (PT_FN_RAND01, PT_FN_FRESNEL, PT_FN_SPEC_PROB, PT_FN_SAMPLE_PHONG, PT_FN_EVAL_PHONG, PT_FN_COS_HEMISPHERE,
- PT_FN_LAMBERT, PT_FN_SKY, PT_FN_PRIMARY_RAY, PT_FN_SKY_VIEW_LUT) = range(10)
-FN_IN_WIDTH = [4, 6, 4, 6, 10, 5, 9, 6, 4, 6]
-FN_OUT_WIDTH = [8, 1, 1, 4, 1, 3, 4, 3, 6, 3]
+ PT_FN_LAMBERT, PT_FN_SKY, PT_FN_PRIMARY_RAY, PT_FN_SKY_VIEW_LUT, PT_FN_GGX_SAMPLE, PT_FN_ALBEDO_PATTERN) = range(12)
+FN_IN_WIDTH = [4, 6, 4, 6, 10, 5, 9, 6, 4, 6, 14, 4]
+FN_OUT_WIDTH = [8, 1, 1, 4, 1, 3, 4, 3, 6, 3, 8, 1]
 
 TLUT_W, TLUT_H = 256, 64
 
@@ -103,6 +103,14 @@ class PtMaterial(C.Structure):
     _fields_ = [("myEmission", C.c_float * 3), ("myColor", C.c_uint32)]
 
 
+PT_MAT_GGX = 1
+
+
+class PtMaterialExt(C.Structure):   # extension for BASELINE C4/C5, not in the reference (include/pt_api.h)
+    _fields_ = [("roughness", C.c_float), ("metallic", C.c_float), ("albedo_pattern", C.c_uint32),
+                ("pattern_scale", C.c_float), ("flags", C.c_uint32), ("reserved", C.c_uint32 * 3)]
+
+
 class PtStats(C.Structure):
     _fields_ = [("samples", C.c_uint64), ("rays", C.c_uint64), ("shaded_hits", C.c_uint64), ("sky_misses", C.c_uint64),
                 ("nodes_visited", C.c_uint64), ("tris_tested", C.c_uint64), ("extend_launches", C.c_uint64),
@@ -135,6 +143,7 @@ SYMBOLS = {
     "pt_set_option": (C.c_int, [_P, C.c_int, C.c_int64]),
     "pt_scene_create": (C.c_int, [_P, C.POINTER(PtMeshDesc), C.c_uint32, C.POINTER(PtInstanceDesc), C.c_uint32,
                                   C.POINTER(PtMaterial), C.c_uint32, C.c_uint32]),
+    "pt_scene_set_material_ext": (C.c_int, [_P, C.POINTER(PtMaterialExt), C.c_uint32]),
     "pt_scene_info": (C.c_int, [_P, C.POINTER(PtSceneInfo)]),
     "pt_sky_set": (C.c_int, [_P, C.POINTER(PtAtmosphere)]),
     "pt_sky_lut_read": (C.c_int, [_P, _P]),

@@ -22,6 +22,9 @@ class SceneData:
                           for m, mat, t in instances]
         self.materials = [(tuple(float(x) for x in e), tuple(float(x) for x in c)) for e, c in materials]
         self.name = name
+        # optional material extension (not in the reference): one (roughness, metallic, albedo_pattern, pattern_scale,
+        # flags) tuple per material, see include/pt_api.h PtMaterialExt
+        self.materials_ext = None
 
     @property
     def num_triangles(self):
@@ -35,6 +38,18 @@ def encode_unorm_rgba(c):
         v = min(max(float(c[k]) if k < len(c) else 1.0, 0.0), 1.0)
         out |= int(np.floor(np.float32(v) * np.float32(255.0) + np.float32(0.5))) << (8 * k)
     return out
+
+
+def pack_material_ext(scene):
+    """SceneData.materials_ext -> ctypes array of PtMaterialExt, or None."""
+    if not getattr(scene, "materials_ext", None):
+        return None
+    assert len(scene.materials_ext) == len(scene.materials)
+    arr = (api.PtMaterialExt * len(scene.materials_ext))()
+    for i, (rough, metal, pattern, scale, flags) in enumerate(scene.materials_ext):
+        arr[i].roughness, arr[i].metallic = float(rough), float(metal)
+        arr[i].albedo_pattern, arr[i].pattern_scale, arr[i].flags = int(pattern), float(scale), int(flags)
+    return arr
 
 
 def pack_scene(scene):
@@ -92,6 +107,13 @@ class Context:
         m, nm, i, ni, mt, nmt, keep = pack_scene(scene)
         self._ck(self.lib.pt_scene_create(self.h, m, nm, i, ni, mt, nmt, flags))
         del keep
+        ext = pack_material_ext(scene)
+        if ext is not None:
+            self._ck(self.lib.pt_scene_set_material_ext(self.h, ext, len(ext)))
+
+    def scene_set_material_ext(self, scene_or_none):
+        ext = pack_material_ext(scene_or_none) if scene_or_none is not None else None
+        self._ck(self.lib.pt_scene_set_material_ext(self.h, ext, len(ext) if ext is not None else 0))
 
     def scene_info(self):
         info = api.PtSceneInfo()

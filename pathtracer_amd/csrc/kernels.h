@@ -16,6 +16,7 @@ struct DeviceScene {
   const uint32_t* instance_material = nullptr;
   const float4* materials = nullptr;   // emission.xyz, rgba8 bits
   const float4* instance_mat4 = nullptr; // materials[instance_material[i]] per instance
+  const float4* instance_ext = nullptr;  // material extension per instance (roughness, metallic, pattern scale, pattern | ggx << 8); null = none
   uint32_t stack_entries = 0;          // stack entries per lane the traversal may need (2 per BVH level + 2)
   uint2* spill = nullptr;              // global spill region of the per-lane stacks: [wave][entry][lane]
 };

@@ -14,6 +14,7 @@
 
 #include "shading_device.h"
 #include "sky_device.h"
+#include "ggx_device.h"
 #include "traverse_device.h"
 
 namespace pt {
@@ -289,6 +290,7 @@ __global__ void __launch_bounds__(256) k_extend(const uint4* __restrict__ nodes,
 }
 
 // ------------------------------------------------------------------------------------------------ shade
+template <bool EXT>
 __global__ void __launch_bounds__(PT_SHADE_THREADS) k_shade(PtRtConsts c, DeviceScene sc, const float4* __restrict__ ray_o_in,
                                                const float4* __restrict__ ray_d_in, const uint32_t* __restrict__ qid_in,
                                                const float4* __restrict__ hits, float4* __restrict__ st_T,
@@ -339,7 +341,23 @@ __global__ void __launch_bounds__(PT_SHADE_THREADS) k_shade(PtRtConsts c, Device
         const float baryZ = 1.0f - (bu + bv);
         v3 hitNormal = bu * mk3(n0.x, n0.y, n0.z) + bv * mk3(n1.x, n1.y, n1.z) + baryZ * mk3(n2.x, n2.y, n2.z);
         const v3 hitPos = origin + dir * hr.x;
-        const v3 color = DecodeUnormRGB(__float_as_uint(mat.w));
+        v3 color = DecodeUnormRGB(__float_as_uint(mat.w));
+        bool ggx = false;
+        float roughness = 0.0f, metallic = 0.0f;
+        if (EXT) {   // material extension (ggx_device.h): procedural albedo from the interpolated uv, GGX flag
+          const float4 ext = sc.instance_ext[instanceId];
+          const uint32_t bits = __float_as_uint(ext.w);
+          if (bits & 0xffu) {
+            const float2 t0 = sc.vertex_uv[pd.x], t1 = sc.vertex_uv[pd.y], t2 = sc.vertex_uv[pd.z];
+            v2 uv;   // LoadInterpolatedVertexData weights (Common.hlsl:121-126), as for the normal
+            uv.x = bu * t0.x + bv * t1.x + baryZ * t2.x;
+            uv.y = bu * t0.y + bv * t1.y + baryZ * t2.y;
+            color = color * AlbedoPattern(bits & 0xffu, ext.z, uv);
+          }
+          ggx = ((bits >> 8) & PT_MAT_GGX_BIT) != 0u;
+          roughness = ext.x;
+          metallic = ext.y;
+        }
         v3 emission = mk3(mat.x, mat.y, mat.z);
         if (dot(hitNormal, -dir) < 0.0f) hitNormal = -hitNormal;
         if (instanceId == c.myLightInstanceId) emission = ld3(c.myLightEmission);
@@ -353,6 +371,10 @@ __global__ void __launch_bounds__(PT_SHADE_THREADS) k_shade(PtRtConsts c, Device
         const float specularStrength = 0.9f;
         const float specularPower = c.myPhongSpecularPower;
         const v3 V = -dir;
+        bool alive = true;
+        if (EXT && ggx) {
+          alive = SampleGgxMaterial(color, roughness, metallic, hitNormal, V, rng, transmission, newDir);
+        } else {
         const float fresnel = GetFresnelSchlick(hitNormal, V);
         const float specRayProbability = EstimateSpecularRayProbability(specularStrength, color, fresnel);
         if (GetRand01(rng) < specRayProbability) {
@@ -375,7 +397,8 @@ __global__ void __launch_bounds__(PT_SHADE_THREADS) k_shade(PtRtConsts c, Device
           u.y = GetRand01(rng);
           newDir = GetCosineWeightedHemisphereDirection(u, hitNormal);
         }
-        const v3 add = transmission * emission;   // :108 — after the throughput update (Q3)
+        }
+        const v3 add = alive ? transmission * emission : mk3(0.0f);   // :108 — after the throughput update (Q3)
         if (!(add.x == 0.0f && add.y == 0.0f && add.z == 0.0f)) {   // L + 0 == L: skip the RMW (a NaN term still lands, Q7)
           float4 Ls = st_L[pid];
           Ls.x += add.x; Ls.y += add.y; Ls.z += add.z;
@@ -383,8 +406,7 @@ __global__ void __launch_bounds__(PT_SHADE_THREADS) k_shade(PtRtConsts c, Device
         }
         // Russian roulette (extension, PT_OPT_RUSSIAN_ROULETTE): the unbiased form of the sketch at PathTracing.hlsl:110-124,
         // same place in the loop, same minBounces = 3: survive with probability q = clamp(lum(T), 0.05, 1), T /= q.
-        bool alive = true;
-        if (russian_roulette && bounce > 3) {
+        if (alive && russian_roulette && bounce > 3) {
           const float q = clampf(GetLuminance(transmission), 0.05f, 1.0f);
           if (GetRand01(rng) >= q) alive = false;
           else transmission = transmission / q;
@@ -632,6 +654,19 @@ __global__ void __launch_bounds__(256) k_debug_eval(int fn, PtRtConsts c, const 
       const v3 L = SampleSkyLuminanceViewLut(ld3(r), ld3(r + 3), c, skyview, MakeSkyViewFrame(c));
       out[3 * i] = L.x; out[3 * i + 1] = L.y; out[3 * i + 2] = L.z;
     } break;
+    case PT_FN_GGX_SAMPLE: {
+      const float* r = in + 14 * i;
+      Rng rng = InitRNG((uint32_t)r[11], (uint32_t)r[12], (uint32_t)r[13]);
+      v3 T = mk3(1.0f), d = mk3(0.0f);
+      const bool alive = SampleGgxMaterial(ld3(r), r[3], r[4], ld3(r + 5), ld3(r + 8), rng, T, d);
+      float* o = out + 8 * i;
+      o[0] = alive ? 1.0f : 0.0f; o[1] = T.x; o[2] = T.y; o[3] = T.z; o[4] = d.x; o[5] = d.y; o[6] = d.z; o[7] = (float)rng.w;
+    } break;
+    case PT_FN_ALBEDO_PATTERN: {
+      const float* r = in + 4 * i;
+      v2 uv; uv.x = r[2]; uv.y = r[3];
+      out[i] = AlbedoPattern((uint32_t)r[0], r[1], uv);
+    } break;
     case PT_FN_PRIMARY_RAY: {
       const float* r = in + 4 * i;
       v2 px; px.x = r[0]; px.y = r[1];
@@ -704,9 +739,12 @@ void launch_shade(const PtRtConsts& c, const DeviceScene& sc, const WavefrontBuf
   const uint64_t cap = (uint64_t)cfg.num_cus * 8u;
   if (g > cap) g = cap;
   if (g < 1) g = 1;
-  hipLaunchKernelGGL(k_shade, dim3((unsigned)g), dim3(PT_SHADE_THREADS), 0, s, c, sc, wb.ray_o[in], wb.ray_d[in],
-                     bounce == 0 ? (const uint32_t*)nullptr : wb.qid[in], wb.hits, wb.st_T, wb.st_L, wb.ray_o[out], wb.ray_d[out],
-                     wb.qid[out], wb.sky_o, wb.sky_d, wb.counters, bounce, w, h, first_sample, russian_roulette ? 1u : 0u);
+#define PT_LAUNCH_SHADE(E)                                                                                                  \
+  hipLaunchKernelGGL(k_shade<E>, dim3((unsigned)g), dim3(PT_SHADE_THREADS), 0, s, c, sc, wb.ray_o[in], wb.ray_d[in],        \
+                     bounce == 0 ? (const uint32_t*)nullptr : wb.qid[in], wb.hits, wb.st_T, wb.st_L, wb.ray_o[out], wb.ray_d[out], \
+                     wb.qid[out], wb.sky_o, wb.sky_d, wb.counters, bounce, w, h, first_sample, russian_roulette ? 1u : 0u)
+  if (sc.instance_ext) PT_LAUNCH_SHADE(true); else PT_LAUNCH_SHADE(false);
+#undef PT_LAUNCH_SHADE
 }
 
 void launch_ao_primary(const PtRtConsts& c, const WavefrontBuffers& wb, uint64_t n_paths, const LaunchCfg& cfg, hipStream_t s) {

@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
+#include <cmath>
 #include <string>
 #include <utility>
 #include <vector>
@@ -31,6 +32,9 @@ struct pt_ctx {
   bool has_scene = false;
   DeviceScene ds;
   std::vector<void*> scene_allocs;
+  std::vector<uint32_t> instance_material;   // host copy, for pt_scene_set_material_ext
+  uint32_t num_materials = 0;
+  float4* instance_ext = nullptr;
   PtSceneInfo info{};
 
   // sky
@@ -300,6 +304,7 @@ int pt_destroy(pt_ctx* ctx) {
   collect_events(ctx);
   for (auto& p : ctx->event_pool) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
   free_list(ctx->scene_allocs);
+  if (ctx->instance_ext) (void)hipFree(ctx->instance_ext);
   if (ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);
   free_list(ctx->wb_allocs);
   free_list(ctx->wb2_allocs);
@@ -388,6 +393,7 @@ int pt_scene_create(pt_ctx* ctx, const PtMeshDesc* meshes, uint32_t num_meshes, 
 
   PT_HIP(hipStreamSynchronize(ctx->stream));
   free_list(ctx->scene_allocs);
+  if (ctx->instance_ext) { (void)hipFree(ctx->instance_ext); ctx->instance_ext = nullptr; }
   ctx->has_scene = false;
   ctx->ds = DeviceScene();
 
@@ -439,6 +445,8 @@ int pt_scene_create(pt_ctx* ctx, const PtMeshDesc* meshes, uint32_t num_meshes, 
     if ((rc = dev_alloc(ctx, &ctx->spill2, waves * ctx->ds.stack_entries * 64u, &ctx->scene_allocs))) return rc;   // pipeline lane 2
   }
   ctx->cfg.extend_blocks = extend_grid(ctx);
+  ctx->instance_material = fs.instance_material;
+  ctx->num_materials = num_materials;
 
   PtSceneInfo& in = ctx->info;
   in.num_triangles = fs.num_triangles();
@@ -451,6 +459,38 @@ int pt_scene_create(pt_ctx* ctx, const PtMeshDesc* meshes, uint32_t num_meshes, 
   for (int a = 0; a < 3; ++a) { in.bounds_min[a] = bvh.lo[a]; in.bounds_max[a] = bvh.hi[a]; }
   in.build_ms = bvh.build_ms;
   ctx->has_scene = true;
+  return PT_OK;
+}
+
+int pt_scene_set_material_ext(pt_ctx* ctx, const PtMaterialExt* ext, uint32_t num_materials) {
+  PT_REQUIRE_CTX();
+  if (!ctx->has_scene) return ctx->fail(PT_ERR_NO_SCENE, "pt_scene_set_material_ext before pt_scene_create");
+  PT_HIP(hipStreamSynchronize(ctx->stream));
+  if (!ext || num_materials == 0) {
+    if (ctx->instance_ext) { (void)hipFree(ctx->instance_ext); ctx->instance_ext = nullptr; }
+    ctx->ds.instance_ext = nullptr;
+    return PT_OK;
+  }
+  if (num_materials != ctx->num_materials) return ctx->fail(PT_ERR_SIZE_MISMATCH, "one PtMaterialExt per material of the scene is required");
+  for (uint32_t m = 0; m < num_materials; ++m) {
+    const PtMaterialExt& e = ext[m];
+    if (!(e.roughness >= 0.0f && e.roughness <= 1.0f) || !(e.metallic >= 0.0f && e.metallic <= 1.0f) || e.albedo_pattern > 2u ||
+        !std::isfinite(e.pattern_scale) || (e.flags & ~PT_MAT_GGX) != 0u)
+      return ctx->fail(PT_ERR_INVALID_ARG, "PtMaterialExt " + std::to_string(m) + ": roughness/metallic outside [0,1], unknown pattern or flag");
+  }
+  std::vector<float> rows(ctx->instance_material.size() * 4);   // resolved per instance, like instance_mat4
+  for (size_t i = 0; i < ctx->instance_material.size(); ++i) {
+    const PtMaterialExt& e = ext[ctx->instance_material[i]];
+    const uint32_t bits = (e.albedo_pattern & 0xffu) | ((e.flags & PT_MAT_GGX) << 8);
+    rows[4 * i] = e.roughness; rows[4 * i + 1] = e.metallic; rows[4 * i + 2] = e.pattern_scale;
+    memcpy(&rows[4 * i + 3], &bits, 4);
+  }
+  if (!ctx->instance_ext) {
+    int rc;
+    if ((rc = dev_alloc(ctx, &ctx->instance_ext, ctx->instance_material.size(), nullptr))) return rc;
+  }
+  if (!rows.empty()) PT_HIP(hipMemcpy(ctx->instance_ext, rows.data(), rows.size() * 4, hipMemcpyHostToDevice));
+  ctx->ds.instance_ext = ctx->instance_ext;
   return PT_OK;
 }
 
@@ -750,8 +790,8 @@ int pt_occluded(pt_ctx* ctx, const PtRay* rays, uint64_t num_rays, uint8_t* occl
 
 int pt_debug_eval(pt_ctx* ctx, int fn, const PtRtConsts* consts, const float* in, uint64_t n, float* out) {
   PT_REQUIRE_CTX();
-  static const int in_w[PT_FN_COUNT] = {4, 6, 4, 6, 10, 5, 9, 6, 4, 6};
-  static const int out_w[PT_FN_COUNT] = {8, 1, 1, 4, 1, 3, 4, 3, 6, 3};
+  static const int in_w[PT_FN_COUNT] = {4, 6, 4, 6, 10, 5, 9, 6, 4, 6, 14, 4};
+  static const int out_w[PT_FN_COUNT] = {8, 1, 1, 4, 1, 3, 4, 3, 6, 3, 8, 1};
   if (fn < 0 || fn >= PT_FN_COUNT) return ctx->fail(PT_ERR_INVALID_ARG, "unknown function id");
   if (n == 0) return PT_OK;
   if (!in || !out) return ctx->fail(PT_ERR_INVALID_ARG, "null array");

@@ -420,6 +420,20 @@ def courtyard(seed=3, target_tris=10485760):
 COURTYARD_CAM = {"eye": (-34.0, 1.7, -24.0), "target": (10.0, 6.0, 8.0)}
 
 
+def with_material_ext(scene, seed=7):
+    """Attach the C4/C5 material extension (GGX + procedural albedo; not in the reference) to a scene: per material a
+    roughness in [0.08, 0.9], one in five metallic, albedo pattern cycling none / checker / value noise, two in three
+    shaded with GGX (the rest keep the reference's Lambert + Phong so both models are exercised)."""
+    n = len(scene.materials)
+    i = np.arange(n)
+    rough = 0.08 + 0.82 * _rand01(seed, 1, i)
+    metal = (_rand01(seed, 2, i) < 0.2).astype(np.float64)
+    scale = 2.0 + np.floor(6.0 * _rand01(seed, 3, i))
+    scene.materials_ext = [(float(rough[k]), float(metal[k]), int(k % 3), float(scale[k]), api.PT_MAT_GGX if k % 3 != 2 else 0)
+                           for k in range(n)]
+    return scene
+
+
 def random_triangle_soup(seed, n, extent=10.0, size=1.0):
     """n random triangles in a cube — intersection-parity tests."""
     i = np.arange(n)

@@ -85,6 +85,17 @@ def function_inputs(fn, n, seed):
         return np.concatenate([pos, d], axis=1).astype(np.float32)
     if fn == api.PT_FN_PRIMARY_RAY:
         return np.stack([rng.uniform(0, 64, n), rng.uniform(0, 64, n), np.full(n, 64), np.full(n, 64)], axis=1).astype(np.float32)
+    if fn == api.PT_FN_GGX_SAMPLE:
+        base = rng.uniform(0.05, 1.0, (n, 3))
+        rough = rng.uniform(0.0, 1.0, (n, 1))
+        metal = (rng.uniform(0, 1, (n, 1)) < 0.3).astype(np.float64)
+        N = _unit(rng, n) * rng.uniform(0.8, 1.0, (n, 1))
+        V = _unit(rng, n)
+        V = np.where((np.sum(N * V, axis=1, keepdims=True) < 0), -V, V)     # ClosestHit flips the normal towards the viewer
+        seeds = np.stack([rng.integers(0, 4096, n), rng.integers(0, 4096, n), rng.integers(0, 1 << 20, n)], axis=1)
+        return np.concatenate([base, rough, metal, N, V, seeds], axis=1).astype(np.float32)
+    if fn == api.PT_FN_ALBEDO_PATTERN:
+        return np.stack([rng.integers(0, 3, n), rng.uniform(0.5, 16.0, n), rng.uniform(-3, 3, n), rng.uniform(-3, 3, n)], axis=1).astype(np.float32)
     raise ValueError(fn)
 
 

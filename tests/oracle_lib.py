@@ -7,7 +7,7 @@ import subprocess
 import numpy as np
 
 from pathtracer_amd import api
-from pathtracer_amd.context import pack_scene
+from pathtracer_amd.context import pack_material_ext, pack_scene
 
 _ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 _DIR = os.path.join(_ROOT, "oracle")
@@ -39,6 +39,8 @@ def load():
     lib.orc_scene_create.argtypes = [C.POINTER(api.PtMeshDesc), C.c_uint32, C.POINTER(api.PtInstanceDesc), C.c_uint32,
                                      C.POINTER(api.PtMaterial), C.c_uint32, C.c_uint32]
     lib.orc_scene_destroy.argtypes = [P]
+    lib.orc_scene_set_material_ext.restype = C.c_int
+    lib.orc_scene_set_material_ext.argtypes = [P, C.POINTER(api.PtMaterialExt), C.c_uint32]
     lib.orc_scene_num_triangles.restype = C.c_uint32
     lib.orc_scene_num_triangles.argtypes = [P]
     lib.orc_scene_triangle.argtypes = [P, C.c_uint32, P, P]
@@ -74,6 +76,9 @@ class OracleScene:
         if not self.h:
             raise ValueError("orc_scene_create rejected the scene")
         self.num_triangles = lib.orc_scene_num_triangles(self.h)
+        ext = pack_material_ext(scene)
+        if ext is not None:
+            assert lib.orc_scene_set_material_ext(self.h, ext, len(ext)) == 0
 
     def __del__(self):
         if getattr(self, "h", None):

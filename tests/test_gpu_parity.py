@@ -342,6 +342,49 @@ def oracle_all_samples_hit(osc, c, w, h, first, spp):
     return m
 
 
+# ---------------------------------------------------------------------------------------------- material extension (GGX, patterns)
+def test_ggx_and_pattern_functions_match_oracle(ctx, oracle):
+    """Extension beyond the reference (ggx_device.h <-> oracle/ggx.h): the procedural albedo and the lobe decision
+    are pure fp32 arithmetic + the integer hash (exact); sampled directions go through sin/cos/sqrt (rtol 5e-5)."""
+    x = function_inputs(api.PT_FN_ALBEDO_PATTERN, 4096, 21)
+    assert np.array_equal(ctx.debug_eval(api.PT_FN_ALBEDO_PATTERN, x), oracle.eval(api.PT_FN_ALBEDO_PATTERN, x))
+    x = function_inputs(api.PT_FN_GGX_SAMPLE, 20000, 22)
+    d = ctx.debug_eval(api.PT_FN_GGX_SAMPLE, x)
+    o = oracle.eval(api.PT_FN_GGX_SAMPLE, x)
+    assert np.array_equal(d[:, 7], o[:, 7])
+    same = d[:, 0] == o[:, 0]                       # alive flag: may flip only for directions grazing the surface
+    assert same.mean() > 0.9995
+    np.testing.assert_allclose(d[same, 1:7], o[same, 1:7], rtol=5e-5, atol=2e-6)
+
+
+def test_material_extension_image_matches_oracle(ctx, oracle):
+    sc = scenes.with_material_ext(scenes.atrium(1))
+    ctx.scene_create(sc)
+    osc = oracle.scene(sc)
+    atm = oracle.earth_atmosphere()
+    ctx.sky_set(atm)
+    olut = oracle.transmittance_lut(atm)
+    w, h, spp = 200, 112, 4
+    c = lookat_consts(w, h, scenes.ATRIUM_CAM)
+    ctx.accum_reset(w, h)
+    ctx.stats_reset()
+    ctx.render(c, w, h, 0, spp)
+    img = ctx.accum_read()
+    st = ctx.stats()
+    acc, ost, _ = osc.render(c, w, h, 0, spp, lut=olut)
+    assert abs(st.rays - ost["rays"]) <= 1e-4 * ost["rays"]
+    assert rel_mse(img, acc / spp) < 1e-4, rel_mse(img, acc / spp)
+    plain = scenes.atrium(1)
+    ctx.scene_create(plain)                             # a new scene drops the extension
+    ctx.accum_reset(w, h)
+    ctx.render(c, w, h, 0, spp)
+    base = ctx.accum_read()
+    assert rel_mse(base, acc / spp) > 1e-3              # the extension does change the picture
+    plain.materials_ext = [(2.0, 0.0, 0, 1.0, 0)] * len(plain.materials)      # roughness outside [0, 1]
+    with pytest.raises(api.PtError):
+        ctx.scene_set_material_ext(plain)
+
+
 # ---------------------------------------------------------------------------------------------- two pipeline lanes
 def test_pipeline_lanes_are_bit_identical_to_single_lane(ctx, oracle):
     """PT_OPT_PIPELINE splits a batch over two streams; the halves are resolved in sample order, so the target and

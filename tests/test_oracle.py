@@ -249,3 +249,35 @@ def test_ao_and_russian_roulette_regression_pins(oracle):
             assert abs(float(acc[..., :3].astype(np.float64).sum()) - pin[str(on)]["sum_rgb"]) <= 1e-6 * abs(pin[str(on)]["sum_rgb"])
     finally:
         oracle.set_russian_roulette(0)
+
+
+def test_material_extension_sanity(oracle):
+    """GGX + procedural albedo (extension, no reference counterpart): sampled directions are unit length and above
+    the surface, every call makes exactly three RNG draws, a white metal never gains energy on average, patterns stay
+    in [0.35, 1], and a scene without PT_MAT_GGX materials and without patterns renders exactly as without the
+    extension."""
+    x = function_inputs(api.PT_FN_GGX_SAMPLE, 50000, 1)
+    y = oracle.eval(api.PT_FN_GGX_SAMPLE, x)
+    alive = y[:, 0] > 0
+    assert 0.9 < alive.mean() <= 1.0
+    assert np.all(y[:, 7] == 3.0)
+    n = x[:, 5:8] / np.linalg.norm(x[:, 5:8], axis=1, keepdims=True)
+    assert np.abs(np.linalg.norm(y[alive, 4:7], axis=1) - 1.0).max() < 1e-5
+    assert (n[alive] * y[alive, 4:7]).sum(1).min() > -1e-5
+    assert np.isfinite(y).all() and (y[:, 1:4] >= 0).all()
+    x2 = x.copy()
+    x2[:, 0:3] = 1.0
+    x2[:, 4] = 1.0
+    y2 = oracle.eval(api.PT_FN_GGX_SAMPLE, x2)
+    assert (y2[:, 1] * (y2[:, 0] > 0)).mean() <= 1.0
+    p = oracle.eval(api.PT_FN_ALBEDO_PATTERN, function_inputs(api.PT_FN_ALBEDO_PATTERN, 20000, 2))
+    assert p.min() >= 0.35 and p.max() <= 1.0
+    sc = scenes.cornell_box()
+    c = cornell_consts(48, 48)
+    a, st_a, _ = oracle.scene(sc).render(c, 48, 48, 0, 2)
+    sc.materials_ext = [(0.5, 0.0, 0, 1.0, 0)] * len(sc.materials)      # extension present but inert
+    b, st_b, _ = oracle.scene(sc).render(c, 48, 48, 0, 2)
+    assert np.array_equal(a, b) and st_a["rays"] == st_b["rays"]
+    sc.materials_ext = [(0.3, 0.0, 1, 0.05, api.PT_MAT_GGX)] * len(sc.materials)
+    g, st_g, _ = oracle.scene(sc).render(c, 48, 48, 0, 2)
+    assert np.isfinite(g).all() and not np.array_equal(a, g)
