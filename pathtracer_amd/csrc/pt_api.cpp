@@ -13,6 +13,9 @@
 #include <vector>
 
 #include "../../include/pt_api.h"
+#ifndef PT_NODE_STRIDE_U4
+#define PT_NODE_STRIDE_U4 5
+#endif
 #include "bvh_builder.h"
 #include "kernels.h"
 #include "scene_flatten.h"
@@ -401,7 +404,7 @@ int pt_scene_create(pt_ctx* ctx, const PtMeshDesc* meshes, uint32_t num_meshes, 
   float4 *d_vn, *d_mat, *d_imat;
   float2* d_uv;
   uint32_t* d_im;
-  if ((rc = dev_alloc(ctx, &d_nodes, bvh.nodes.size() * 5, &ctx->scene_allocs))) return rc;
+  if ((rc = dev_alloc(ctx, &d_nodes, bvh.nodes.size() * PT_NODE_STRIDE_U4, &ctx->scene_allocs))) return rc;
   if ((rc = dev_alloc(ctx, &d_tris, bvh.tris.size() * 3, &ctx->scene_allocs))) return rc;
   if ((rc = dev_alloc(ctx, &d_prim, (size_t)fs.num_triangles(), &ctx->scene_allocs))) return rc;
   if ((rc = dev_alloc(ctx, &d_vn, (size_t)fs.num_vertices(), &ctx->scene_allocs))) return rc;
@@ -416,7 +419,15 @@ int pt_scene_create(pt_ctx* ctx, const PtMeshDesc* meshes, uint32_t num_meshes, 
   auto up = [&](void* dst, const void* src, size_t bytes) -> hipError_t {
     return bytes ? hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice) : hipSuccess;
   };
+#if PT_NODE_STRIDE_U4 == 5
   PT_HIP(up(d_nodes, bvh.nodes.data(), bvh.nodes.size() * sizeof(PtBvh8Node)));
+#else
+  {
+    std::vector<uint8_t> padded(bvh.nodes.size() * PT_NODE_STRIDE_U4 * 16, 0);
+    for (size_t i = 0; i < bvh.nodes.size(); ++i) memcpy(&padded[i * PT_NODE_STRIDE_U4 * 16], &bvh.nodes[i], sizeof(PtBvh8Node));
+    PT_HIP(up(d_nodes, padded.data(), padded.size()));
+  }
+#endif
   PT_HIP(up(d_tris, bvh.tris.data(), bvh.tris.size() * sizeof(PtTriRecord)));
   PT_HIP(up(d_prim, fs.prim_data.data(), fs.prim_data.size() * 4));
   PT_HIP(up(d_vn, fs.vertex_normal.data(), fs.vertex_normal.size() * 4));

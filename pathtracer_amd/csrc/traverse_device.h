@@ -7,6 +7,10 @@
 #include "bvh8.h"
 #include "device_math.h"
 
+#ifndef PT_NODE_STRIDE_U4
+#define PT_NODE_STRIDE_U4 5   // device stride of a BVH node in 16-byte units (5 = packed 80-byte nodes)
+#endif
+
 namespace ptd {
 
 struct TraceRay {
@@ -135,7 +139,7 @@ struct Traverser {
     if (ng.y > 0x00FFFFFFu) { stk.put(sp, ng); ++sp; }
     const uint32_t slot = ((uint32_t)b - 24u) ^ oct;
     const uint32_t rel = __popc(hits & ~(0xFFFFFFFFu << slot));
-    const uint4* np = nodes + (size_t)(ng.x + rel) * 5;
+    const uint4* np = nodes + (size_t)(ng.x + rel) * PT_NODE_STRIDE_U4;
     const uint4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3], n4 = np[4];
 
     const uint32_t e = n0.w;
