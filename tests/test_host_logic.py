@@ -189,3 +189,23 @@ def test_host_mirror_defaults_match_reference_header():
     a = SetupEarthAtmosphere()
     assert a.MiePhaseG == np.float32(0.8) and a.AbsorptionDensity0LayerWidth == 25000.0
     assert abs(a.RayleighDensityExpScale + 1 / 8000.0) < 1e-9 and abs(a.MieAbsorption[0] - 4.44e-7) < 1e-9
+
+
+def test_image_io_roundtrip_and_png_signature(tmp_path):
+    from pathtracer_amd import image_io
+    rng = np.random.default_rng(3)
+    img = rng.uniform(0, 5, (7, 9, 4)).astype(np.float32)
+    image_io.write_pfm(tmp_path / "a.pfm", img)
+    assert np.array_equal(image_io.read_pfm(tmp_path / "a.pfm"), img[..., :3])
+    ldr = image_io.tonemap_reinhard(img)
+    assert np.allclose(ldr, img[..., :3] / (img[..., :3] + 1.0)) and ldr.max() < 1.0
+    image_io.write_png(tmp_path / "a.png", ldr)
+    data = open(tmp_path / "a.png", "rb").read()
+    assert data[:8] == b"\x89PNG\r\n\x1a\n" and data[12:16] == b"IHDR" and data[-8:-4] == b"IEND"
+    import struct, zlib
+    w, h = struct.unpack(">II", data[16:24])
+    assert (w, h) == (9, 7)
+    i = data.index(b"IDAT")
+    n = struct.unpack(">I", data[i - 4:i])[0]
+    raw = zlib.decompress(data[i + 4:i + 4 + n])
+    assert len(raw) == h * (1 + 3 * w)
