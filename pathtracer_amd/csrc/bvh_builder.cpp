@@ -32,7 +32,10 @@ static inline float half_area(const float* lo, const float* hi) {
   return dx * dy + dy * dz + dz * dx;
 }
 
-constexpr int kBins = 16;
+#ifndef PT_BVH_BINS
+#define PT_BVH_BINS 16
+#endif
+constexpr int kBins = PT_BVH_BINS;
 constexpr uint32_t kParallelThreshold = 1u << 15;
 
 class Builder2 {
