@@ -284,6 +284,41 @@ def test_atrium_image_vs_oracle(ctx, oracle):
     assert img[..., :3].mean() > 0
 
 
+# ---------------------------------------------------------------------------------------------- schedule options
+@pytest.mark.parametrize("fetch_min,postpone,blocks,lds_stack,defer", [
+    (16, 50, 0, 8, 4),      # shipped defaults
+    (1, 0, 1, 1, 0),        # stack postponing off, one LDS stack entry: everything deeper goes through the global spill
+    (64, 100, 2, 2, 1),     # refill only when the whole wave is idle, always postpone, one parked group
+    (32, 25, 3, 3, 16),     # large deferred queue
+    (8, 75, 0, 128, 0),     # whole stack in LDS (more than 64 KB of dynamic LDS), stack postponing
+])
+def test_extend_schedule_options_never_change_hits(ctx, oracle, fetch_min, postpone, blocks, lds_stack, defer):
+    """The PT_OPT_EXTEND_* values only reorder work inside the traversal kernel: closest hits stay bit-identical to
+    the oracle and occlusion answers stay equal, including through the global stack-spill path."""
+    sc = scenes.atrium(1)
+    ctx.scene_create(sc)
+    osc = oracle.scene(sc)
+    info = ctx.scene_info()
+    rays = random_rays(31, 150000, list(info.bounds_min), list(info.bounds_max), tmin=0.001, tmax=10000.0)
+    ref = osc.trace_rays(rays)
+    opts = ((api.PT_OPT_EXTEND_FETCH_MIN, fetch_min, 16), (api.PT_OPT_EXTEND_POSTPONE_PCT, postpone, 50),
+            (api.PT_OPT_EXTEND_BLOCKS_PER_CU, blocks, 0), (api.PT_OPT_EXTEND_LDS_STACK, lds_stack, 8),
+            (api.PT_OPT_EXTEND_DEFER, defer, 4))
+    try:
+        for o, v, _ in opts:
+            ctx.set_option(o, v)
+        got = ctx.trace_rays(rays)
+        occ = ctx.occluded(rays)
+    finally:
+        for o, _, d in opts:
+            ctx.set_option(o, d)
+    assert np.array_equal(got["prim"], ref["prim"])
+    hit = ref["prim"] != api.PT_MISS
+    for f in ("t", "u", "v"):
+        assert np.array_equal(got[f][hit].view(np.uint32), ref[f][hit].view(np.uint32)), f
+    assert np.array_equal(occ.astype(bool), hit)
+
+
 # ---------------------------------------------------------------------------------------------- AO pipeline (Ao.hlsl)
 def test_occlusion_queries_match_oracle_closest_hit(ctx, oracle):
     """pt_occluded stops at the first accepted intersection; the answer must equal 'the closest-hit query hit
