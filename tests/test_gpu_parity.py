@@ -284,6 +284,39 @@ def test_atrium_image_vs_oracle(ctx, oracle):
     assert img[..., :3].mean() > 0
 
 
+def test_street_3m_triangles_hits_and_image_match_oracle(ctx, oracle):
+    """BASELINE config C4's scene at full triangle count (3,145,728): random incoherent rays bit-identical to the
+    oracle's own BVH, and a small depth-8 image within tolerance. Ray counts may differ by a few paths: bounce
+    directions go through sin/cos/acos/pow (ocml vs libm, last-ulp differences), and over 8 bounces in a 3 M-triangle
+    scene a handful of rays land on the other side of an edge."""
+    sc = scenes.street(2)
+    ctx.scene_create(sc)
+    osc = oracle.scene(sc)
+    info = ctx.scene_info()
+    assert info.num_triangles == 3145728
+    rays = random_rays(41, 200000, list(info.bounds_min), list(info.bounds_max), tmin=0.001, tmax=10000.0)
+    got, ref = ctx.trace_rays(rays), osc.trace_rays(rays)
+    assert np.array_equal(got["prim"], ref["prim"])
+    hit = ref["prim"] != api.PT_MISS
+    assert 0.3 < hit.mean() < 1.0
+    for f in ("t", "u", "v"):
+        assert np.array_equal(got[f][hit].view(np.uint32), ref[f][hit].view(np.uint32)), f
+    atm = oracle.earth_atmosphere()
+    ctx.sky_set(atm)
+    olut = oracle.transmittance_lut(atm)
+    w, h = 160, 90
+    c = lookat_consts(w, h, scenes.STREET_CAM, depth=8)
+    ctx.accum_reset(w, h)
+    ctx.stats_reset()
+    ctx.render(c, w, h, 0, 2)
+    img = ctx.accum_read()
+    st = ctx.stats()
+    acc, ost, _ = osc.render(c, w, h, 0, 2, lut=olut)
+    assert abs(st.rays - ost["rays"]) <= 1e-3 * ost["rays"]
+    assert abs(st.sky_misses - ost["sky_misses"]) <= 1e-3 * ost["sky_misses"] + 2
+    assert rel_mse(img, acc / 2.0) < 1e-4, rel_mse(img, acc / 2.0)
+
+
 # ---------------------------------------------------------------------------------------------- schedule options
 @pytest.mark.parametrize("fetch_min,postpone,blocks,lds_stack,defer", [
     (16, 50, 0, 8, 4),      # shipped defaults
