@@ -5,7 +5,7 @@
 //   generate : InitRNG + jitter + GetPrimaryRay                      (PathTracing.hlsl:43-66)
 //   extend   : TraceRay -> closest hit                               (PathTracing.hlsl:71)        [dominant kernel]
 //   shade    : ClosestHit + BRDF sampling + throughput/emission      (PathTracing.hlsl:16-38,73-127), survivors are
-//              compacted into the next bounce's ray queue with wave-aggregated atomics; misses go to the sky queue
+//              compacted into the next bounce's ray queue with block-aggregated atomics; misses go to the sky queue
 //   sky      : SampleSkyLuminance for every queued miss              (PathTracing.hlsl:75, SampleSky.hlsl:7-47)
 //   resolve  : NaN/Inf scrub + accumulation in sample order          (PathTracing.hlsl:130-137)
 // No kernel needs a host round trip: queue lengths live in device counters and the extend/shade/sky kernels are
@@ -120,9 +120,10 @@ __global__ void __launch_bounds__(256) k_generate(PtRtConsts c, float4* __restri
 // Persistent waves. Each wave owns a local pool of queue slots (claimed from the global cursor in chunks, one atomic
 // per chunk: a single word sustains only ~90 returning atomics/us chip-wide, so per-64-ray claims would bound the
 // kernel) and keeps its 64 lanes busy: lanes whose ray has finished are refilled from the pool once enough of them are
-// idle (fetch_min), and triangle tests are postponed to the LDS stack while fewer than postpone_pct % of the busy
-// lanes have any, so
-// that the wave spends its instructions on box tests or on triangle tests with most lanes active.
+// idle (fetch_min). Two schedules for the triangle tests: DEFER (default) parks triangle groups in a small per-lane
+// queue and runs a triangle phase only when enough lanes have parked work; !DEFER postpones them on the traversal
+// stack while fewer than postpone_pct % of the busy lanes have any. Either way the wave spends its instructions on box
+// tests or on triangle tests with most lanes active.
 
 template <bool COUNT, bool DEFER>
 __global__ void __launch_bounds__(256) k_extend(const uint4* __restrict__ nodes, const uint4* __restrict__ tris,
