@@ -54,3 +54,58 @@ def bind_torch_target(ctx, width, height, device):
     t = torch.zeros(height * width * 4, dtype=torch.float32, device=device)
     ctx.accum_bind(t.data_ptr(), width, height)
     return t
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# GPU-count-independent result: fp32 addition is not associative, so "the 8-GPU image equals the 1-GPU
+# image" only holds bit for bit if the order of additions does not depend on the number of GPUs. The sample range is
+# therefore always cut into VIRTUAL_PARTITIONS fixed blocks; a rank renders each of ITS blocks into a target of its own
+# (samples added in index order), and the root adds the block sums in block order. 1, 2, 4 or 8 ranks give the same bits.
+VIRTUAL_PARTITIONS = 8
+
+
+def rank_partitions(world_size, rank):
+    """Virtual partitions owned by `rank`: a contiguous run, so rank order == partition order."""
+    if VIRTUAL_PARTITIONS % world_size != 0:
+        raise ValueError(f"world size {world_size} must divide {VIRTUAL_PARTITIONS}")
+    per = VIRTUAL_PARTITIONS // world_size
+    return list(range(rank * per, (rank + 1) * per))
+
+
+def render_virtual_partitions(ctx, consts, width, height, total_samples, world_size, rank, device, first_sample=0):
+    """Render this rank's virtual partitions; returns a (len(rank_partitions), H*W*4) float32 tensor of block sums."""
+    mine = rank_partitions(world_size, rank)
+    out = torch.zeros((len(mine), height * width * 4), dtype=torch.float32, device=device)
+    for k, v in enumerate(mine):
+        first, n = partition_samples(total_samples, VIRTUAL_PARTITIONS, v)
+        ctx.accum_bind(out[k].data_ptr(), width, height)      # zeroes the block target
+        if n:
+            ctx.render(consts, width, height, first_sample + first, n)
+    ctx.synchronize()
+    ctx.accum_bind(0, 0, 0)
+    return out
+
+
+def combine_virtual_partitions(block_sums, group=None, root=0):
+    """Gather every rank's block sums on `root` and add them in partition order. Returns the (H*W*4) sum on root,
+    None elsewhere. With one process the blocks are simply added in order."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        parts = [block_sums]
+    else:
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+        if rank == root:
+            parts = [torch.empty_like(block_sums) for _ in range(world)]
+            dist.gather(block_sums, gather_list=parts, dst=root, group=group)
+        else:
+            dist.gather(block_sums, gather_list=None, dst=root, group=group)
+            return None
+    return sum_blocks_in_order(parts)
+
+
+def sum_blocks_in_order(parts):
+    """parts: per-rank (n_blocks, N) tensors in rank order (== partition order). One fixed chain of additions."""
+    total = None
+    for p in parts:
+        for k in range(p.shape[0]):
+            total = p[k].clone() if total is None else total.add_(p[k])
+    return total

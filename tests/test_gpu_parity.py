@@ -482,6 +482,29 @@ def test_pipeline_lanes_are_bit_identical_to_single_lane(ctx, oracle):
     assert out[0][1] == 14
 
 
+def test_virtual_partitions_give_identical_bits_for_1_2_4_8_ranks(ctx, oracle):
+    """SURVEY §8e on the device: the ranks of a 1/2/4/8-GPU job are played one after the other on this GPU."""
+    import torch
+    from pathtracer_amd import distributed as ptd
+    sc = scenes.atrium(1)
+    ctx.scene_create(sc)
+    ctx.sky_set(oracle.earth_atmosphere())
+    w, h, total = 160, 90, 21
+    c = lookat_consts(w, h, scenes.ATRIUM_CAM)
+    dev = torch.device("cuda", 0)
+    ref = None
+    for world in (1, 2, 4, 8):
+        parts = [ptd.render_virtual_partitions(ctx, c, w, h, total, world, r, dev) for r in range(world)]
+        tot = ptd.sum_blocks_in_order(parts).cpu().numpy()
+        ref = tot if ref is None else ref
+        assert np.array_equal(tot, ref), world
+    ctx.accum_reset(w, h)
+    ctx.render(c, w, h, 0, total)
+    single, n = ctx.accum_read_sum()
+    assert n == total
+    assert rel_mse(ref.reshape(h, w, 4), single) < 1e-10
+
+
 # ---------------------------------------------------------------------------------------------- Russian roulette (extension)
 def test_russian_roulette_matches_oracle_and_is_unbiased(ctx, cornell, oracle):
     """PT_OPT_RUSSIAN_ROULETTE: same rays, hits and image as the oracle's restatement (ray counts exact, image to the

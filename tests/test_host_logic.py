@@ -177,6 +177,55 @@ def test_two_rank_gloo_reduce_equals_single_process(tmp_path, oracle):
     assert np.array_equal(red, a + b)      # with two ranks any reduction order gives a+b
 
 
+def _oracle_block_sums(osc, c, W, H, total, world, rank):
+    import torch
+    from pathtracer_amd import distributed as ptd
+    rows = []
+    for v in ptd.rank_partitions(world, rank):
+        first, n = ptd.partition_samples(total, ptd.VIRTUAL_PARTITIONS, v)
+        acc, _, _ = osc.render(c, W, H, first, n)
+        rows.append(torch.from_numpy(acc.reshape(-1).copy()))
+    return torch.stack(rows)
+
+
+def _gloo_vp_worker(rank, world, port, tmp):
+    import torch.distributed as dist
+    from pathtracer_amd import distributed as ptd
+    from tests import oracle_lib
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    osc = oracle_lib.load().scene(scenes.cornell_box())
+    blocks = _oracle_block_sums(osc, cornell_consts(24, 24), 24, 24, 19, world, rank)
+    total = ptd.combine_virtual_partitions(blocks)
+    if rank == 0:
+        np.save(os.path.join(tmp, "vp.npy"), total.numpy())
+    else:
+        assert total is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_virtual_partitions_make_the_sum_independent_of_rank_count(tmp_path, oracle):
+    """8 fixed virtual partitions combined in a fixed order -> the same bits for 1, 2, 4 or 8 ranks.
+    World sizes 1, 4 and 8 are simulated in-process; world size 2 runs under gloo (the per-rank renderer is the oracle)."""
+    import torch.multiprocessing as mp
+    from pathtracer_amd import distributed as ptd
+    osc = oracle.scene(scenes.cornell_box())
+    c = cornell_consts(24, 24)
+    ref = None
+    for world in (1, 4, 8):
+        parts = [_oracle_block_sums(osc, c, 24, 24, 19, world, r) for r in range(world)]
+        tot = ptd.sum_blocks_in_order(parts).numpy()
+        ref = tot if ref is None else ref
+        assert np.array_equal(tot, ref), world
+    port = 31500 + (os.getpid() % 2000)
+    mp.spawn(_gloo_vp_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert np.array_equal(np.load(tmp_path / "vp.npy"), ref)
+    single, _, _ = osc.render(c, 24, 24, 0, 19)                      # one chain of 19 additions: close, not identical
+    np.testing.assert_allclose(ref.reshape(24, 24, 4), single, rtol=3e-6, atol=1e-6)
+    with pytest.raises(ValueError):
+        ptd.rank_partitions(3, 0)
+
+
 def test_host_mirror_defaults_match_reference_header():
     """PathTracer.h:112-131 and Sky.h:80-83 defaults, checked on the class source without creating a GPU ctx."""
     import inspect
