@@ -263,6 +263,13 @@ int pt_accum_read(pt_ctx* ctx, float* host_rgba_mean);
 /* Raw sum -> host. */
 int pt_accum_read_sum(pt_ctx* ctx, float* host_rgba_sum, uint64_t* num_samples);
 
+/* Multi-GPU in ONE process (SURVEY §8b "pt_reduce"; the reference is single-GPU, no counterpart): adds the sum targets
+ * of ctxs[1..n-1] onto ctxs[0] in array order (peer copies into a staging buffer on ctxs[0]'s device + one add kernel
+ * each), adds their sample counts, and waits for completion. All targets must have the same size; the source
+ * contexts keep their targets unchanged. One-process-per-GPU jobs use torch.distributed instead
+ * (pathtracer_amd/distributed.py). */
+int pt_reduce(pt_ctx** ctxs, uint32_t n);
+
 /* ---- the hot path: replaces PathTracer::RenderRT + RayGen/ClosestHit/(miss) (PathTracer.cpp:659-787,
  *      PathTracing.hlsl:16-138). Renders samples first_sample .. first_sample+num_samples-1 of every pixel
  *      (one reference "frame" each) and adds them to the accumulation target. Asynchronous on the ctx stream. ---- */

@@ -155,6 +155,7 @@ SYMBOLS = {
     "pt_accum_read_sum": (C.c_int, [_P, _P, C.POINTER(C.c_uint64)]),
     "pt_render": (C.c_int, [_P, C.POINTER(PtRtConsts), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
     "pt_render_ao": (C.c_int, [_P, C.POINTER(PtRtConsts), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
+    "pt_reduce": (C.c_int, [C.POINTER(_P), C.c_uint32]),
     "pt_primary_hits": (C.c_int, [_P, C.POINTER(PtRtConsts), C.c_uint32, C.c_uint32, C.c_uint32, _P]),
     "pt_trace_rays": (C.c_int, [_P, _P, C.c_uint64, _P]),
     "pt_trace_rays_device": (C.c_int, [_P, _P, C.c_uint64, _P]),

@@ -215,3 +215,12 @@ class Context:
 
     def stats_reset(self):
         self._ck(self.lib.pt_stats_reset(self.h))
+
+
+def reduce_contexts(contexts):
+    """pt_reduce: add the sum targets of contexts[1:] onto contexts[0] (single-process multi-GPU)."""
+    arr = (C.c_void_p * len(contexts))(*[c.h for c in contexts])
+    lib = contexts[0].lib
+    rc = lib.pt_reduce(arr, len(contexts))
+    if rc != api.PT_OK:
+        raise api.PtError(rc, lib.pt_last_error(contexts[0].h).decode())

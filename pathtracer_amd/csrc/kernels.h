@@ -81,6 +81,7 @@ void launch_skyview_lut(const PtRtConsts& c, const uint2* tlut, float4* out, hip
 void launch_sky(const PtRtConsts& c, const uint2* lut, const float4* skyview, const WavefrontBuffers& wb, uint64_t max_paths, const LaunchCfg& cfg, hipStream_t s);
 void launch_resolve(const WavefrontBuffers& wb, float4* accum, uint32_t w, uint32_t h, uint32_t samples_in_batch, uint32_t num_bounces,
                     hipStream_t s);
+void launch_add(float4* dst, const float4* src, uint64_t n, hipStream_t s);   // dst[i] += src[i]
 void launch_set_count(uint32_t* counter, uint32_t value, hipStream_t s);
 void launch_debug_eval(int fn, const PtRtConsts& c, const uint2* lut, const float4* skyview, const float* in, uint64_t n, float* out, hipStream_t s);
 size_t extend_lds_bytes(uint32_t stack_entries);

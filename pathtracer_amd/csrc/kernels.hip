@@ -791,6 +791,19 @@ void launch_resolve(const WavefrontBuffers& wb, float4* accum, uint32_t w, uint3
                      num_bounces);
 }
 
+__global__ void __launch_bounds__(256) k_add(float4* __restrict__ dst, const float4* __restrict__ src, uint64_t n) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float4 a = dst[i];
+  const float4 b = src[i];
+  a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+  dst[i] = a;
+}
+
+void launch_add(float4* dst, const float4* src, uint64_t n, hipStream_t s) {
+  hipLaunchKernelGGL(k_add, dim3(grid_for(n, 0)), dim3(256), 0, s, dst, src, n);
+}
+
 void launch_set_count(uint32_t* counter, uint32_t value, hipStream_t s) {
   hipLaunchKernelGGL(k_set_count, dim3(1), dim3(1), 0, s, counter, value);
 }

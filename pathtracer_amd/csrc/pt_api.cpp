@@ -731,6 +731,40 @@ int pt_render_ao(pt_ctx* ctx, const PtRtConsts* consts, uint32_t width, uint32_t
   return PT_OK;
 }
 
+int pt_reduce(pt_ctx** ctxs, uint32_t n) {
+  if (!ctxs || n == 0 || !ctxs[0]) return PT_ERR_INVALID_ARG;
+  pt_ctx* ctx = ctxs[0];   // errors are reported on the destination context
+  if (!ctx->accum) return ctx->fail(PT_ERR_NO_TARGET, "pt_reduce: ctxs[0] has no accumulation target");
+  for (uint32_t i = 1; i < n; ++i) {
+    if (!ctxs[i]) return ctx->fail(PT_ERR_INVALID_ARG, "pt_reduce: null context");
+    if (!ctxs[i]->accum) return ctx->fail(PT_ERR_NO_TARGET, "pt_reduce: a source context has no accumulation target");
+    if (ctxs[i]->width != ctx->width || ctxs[i]->height != ctx->height) return ctx->fail(PT_ERR_SIZE_MISMATCH, "pt_reduce: target sizes differ");
+    if (ctxs[i] == ctx) return ctx->fail(PT_ERR_INVALID_ARG, "pt_reduce: ctxs[0] appears twice");
+  }
+  const size_t texels = (size_t)ctx->width * ctx->height;
+  for (uint32_t i = 1; i < n; ++i) {   // everything queued on the sources must have landed before their targets are read
+    if (hipSetDevice(ctxs[i]->device) != hipSuccess || hipStreamSynchronize(ctxs[i]->stream) != hipSuccess)
+      return ctx->fail(PT_ERR_HIP, "pt_reduce: cannot synchronise a source context");
+  }
+  PT_REQUIRE_CTX();
+  float4* staging = nullptr;
+  int rc;
+  if (n > 1 && (rc = dev_alloc(ctx, &staging, texels, nullptr))) return rc;
+  hipError_t e = hipSuccess;
+  for (uint32_t i = 1; i < n && e == hipSuccess; ++i) {
+    e = hipMemcpyPeerAsync(staging, ctx->device, ctxs[i]->accum, ctxs[i]->device, texels * sizeof(float4), ctx->stream);
+    if (e == hipSuccess) {
+      launch_add(ctx->accum, staging, texels, ctx->stream);
+      e = hipGetLastError();
+    }
+    if (e == hipSuccess) ctx->num_samples += ctxs[i]->num_samples;
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  if (staging) (void)hipFree(staging);
+  if (e != hipSuccess) return ctx->fail(PT_ERR_HIP, std::string("pt_reduce: ") + hipGetErrorString(e));
+  return PT_OK;
+}
+
 int pt_primary_hits(pt_ctx* ctx, const PtRtConsts* consts, uint32_t width, uint32_t height, uint32_t sample, PtHit* hits) {
   PT_REQUIRE_CTX();
   int rc = check_consts(ctx, consts, false);

@@ -482,6 +482,33 @@ def test_pipeline_lanes_are_bit_identical_to_single_lane(ctx, oracle):
     assert out[0][1] == 14
 
 
+def test_pt_reduce_adds_targets_of_several_contexts(ctx, cornell):
+    """pt_reduce (single-process multi-GPU): two more contexts on this device stand in for two more GPUs."""
+    from pathtracer_amd.context import Context, reduce_contexts
+    sc, _ = cornell
+    w, h = 64, 48
+    c = cornell_consts(w, h)
+    others = [Context(0), Context(0)]
+    try:
+        parts = []
+        for k, cx in enumerate([ctx] + others):
+            cx.scene_create(sc)
+            cx.accum_reset(w, h)
+            cx.render(c, w, h, 4 * k, 4)
+            parts.append(cx.accum_read_sum()[0])
+        reduce_contexts([ctx] + others)
+        total, n = ctx.accum_read_sum()
+        assert n == 12
+        assert np.array_equal(total, (parts[0] + parts[1]) + parts[2])
+        assert np.array_equal(others[0].accum_read_sum()[0], parts[1])        # sources untouched
+        others[1].accum_reset(w + 1, h)
+        with pytest.raises(api.PtError):
+            reduce_contexts([ctx] + others)
+    finally:
+        for cx in others:
+            cx.close()
+
+
 def test_virtual_partitions_give_identical_bits_for_1_2_4_8_ranks(ctx, oracle):
     """SURVEY §8e on the device: the ranks of a 1/2/4/8-GPU job are played one after the other on this GPU."""
     import torch
