@@ -27,8 +27,10 @@ struct Prim {
   float lo[3], hi[3], c[3];
 };
 
-static inline float half_area(const float* lo, const float* hi) {
-  float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+// Areas and SAH costs are doubles: a single far-away (but finite) vertex makes fp32 areas overflow to +inf, and an
+// infinite cost poisons every comparison of the builder and of the collapse.
+static inline double half_area(const float* lo, const float* hi) {
+  const double dx = (double)hi[0] - lo[0], dy = (double)hi[1] - lo[1], dz = (double)hi[2] - lo[2];
   return dx * dy + dy * dz + dz * dx;
 }
 
@@ -125,16 +127,16 @@ class Builder2 {
       }
     }
     int bestAxis = -1, bestSplit = -1;
-    float bestCost = FLT_MAX;
+    double bestCost = DBL_MAX;
     for (int a = 0; a < 3; ++a) {
       if (scale[a] == 0.0f) continue;
-      float rarea[kBins]; uint32_t rcnt[kBins];
+      double rarea[kBins]; uint32_t rcnt[kBins];
       float l3[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, h3[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
       uint32_t c = 0;
       for (int b = kBins - 1; b > 0; --b) {
         for (int k = 0; k < 3; ++k) { l3[k] = std::min(l3[k], bins[a][b].lo[k]); h3[k] = std::max(h3[k], bins[a][b].hi[k]); }
         c += bins[a][b].n;
-        rarea[b] = c ? half_area(l3, h3) : 0.0f;
+        rarea[b] = c ? half_area(l3, h3) : 0.0;
         rcnt[b] = c;
       }
       for (int k = 0; k < 3; ++k) { l3[k] = FLT_MAX; h3[k] = -FLT_MAX; }
@@ -143,7 +145,7 @@ class Builder2 {
         for (int k = 0; k < 3; ++k) { l3[k] = std::min(l3[k], bins[a][b].lo[k]); h3[k] = std::max(h3[k], bins[a][b].hi[k]); }
         c += bins[a][b].n;
         if (c == 0 || rcnt[b + 1] == 0) continue;
-        float cost = half_area(l3, h3) * (float)c + rarea[b + 1] * (float)rcnt[b + 1];
+        const double cost = half_area(l3, h3) * (double)c + rarea[b + 1] * (double)rcnt[b + 1];
         if (cost < bestCost) { bestCost = cost; bestAxis = a; bestSplit = b; }
       }
     }
@@ -217,20 +219,27 @@ void build_bvh8(const float* verts, uint32_t n, Bvh8& out, int num_threads) {
   out.tris.clear();
   out.max_depth = 0;
 
-  // ---- scene bounds and the conservative pad (see DESIGN.md "box conservativeness") ----
+  // ---- active triangles, scene bounds and the conservative pad (see DESIGN.md "box conservativeness") ----
+  // A triangle with a NaN or infinite vertex can never be hit (every comparison of the intersection test fails), so it
+  // is left out of the hierarchy — DXR calls such primitives inactive. Its id stays reserved.
+  std::vector<uint32_t> order;
+  order.reserve(n);
   float slo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, shi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
-  for (size_t i = 0; i < (size_t)n * 3; ++i)
-    for (int a = 0; a < 3; ++a) {
-      float v = verts[i * 3 + a];
-      slo[a] = std::min(slo[a], v); shi[a] = std::max(shi[a], v);
-    }
-  if (n == 0) { for (int a = 0; a < 3; ++a) { slo[a] = 0; shi[a] = 0; } }
+  for (uint32_t i = 0; i < n; ++i) {
+    const float* v = verts + (size_t)i * 9;
+    bool finite = true;
+    for (int k = 0; k < 9; ++k) finite = finite && std::isfinite(v[k]);
+    if (!finite) continue;
+    order.push_back(i);
+    for (int k = 0; k < 9; ++k) { slo[k % 3] = std::min(slo[k % 3], v[k]); shi[k % 3] = std::max(shi[k % 3], v[k]); }
+  }
+  if (order.empty()) { for (int a = 0; a < 3; ++a) { slo[a] = 0; shi[a] = 0; } }
   float mag = 0.0f;
   for (int a = 0; a < 3; ++a) mag = std::max(mag, std::max(std::fabs(slo[a]), std::fabs(shi[a])));
   const float pad = 4e-6f * std::max(mag, 1e-3f);
   for (int a = 0; a < 3; ++a) { out.lo[a] = slo[a]; out.hi[a] = shi[a]; }
 
-  if (n == 0) {
+  if (order.empty()) {
     PtBvh8Node root;
     memset(&root, 0, sizeof(root));
     root.e[0] = root.e[1] = root.e[2] = 127;
@@ -241,18 +250,16 @@ void build_bvh8(const float* verts, uint32_t n, Bvh8& out, int num_threads) {
   }
 
   std::vector<Prim> prims(n);
-  for (uint32_t i = 0; i < n; ++i) {
+  for (uint32_t i : order) {
     const float* v = verts + (size_t)i * 9;
     for (int a = 0; a < 3; ++a) {
       float lo = std::min(v[a], std::min(v[3 + a], v[6 + a]));
       float hi = std::max(v[a], std::max(v[3 + a], v[6 + a]));
       prims[i].lo[a] = lo - pad;
       prims[i].hi[a] = hi + pad;
-      prims[i].c[a] = 0.5f * (lo + hi);
+      prims[i].c[a] = 0.5f * lo + 0.5f * hi;   // not 0.5*(lo+hi): the sum can overflow for |coordinates| near FLT_MAX
     }
   }
-  std::vector<uint32_t> order(n);
-  for (uint32_t i = 0; i < n; ++i) order[i] = i;
   std::vector<Node2> n2;
   Builder2(prims, order, n2, num_threads).run();
   const uint32_t nn = (uint32_t)n2.size();
@@ -260,34 +267,34 @@ void build_bvh8(const float* verts, uint32_t n, Bvh8& out, int num_threads) {
   // ---- SAH-optimal collapse (dynamic programme over "up to i roots", i = 1..7) ----
   // SAH constants of the collapse: cost of one 8-wide node step vs one triangle test. PT_BVH_CPRIM overrides the
   // triangle cost for tuning runs (tools/tune_bvh.sh).
-  float Cnode = 1.0f, Cprim = 0.3f;
-  if (const char* e = getenv("PT_BVH_CPRIM")) { const float v = (float)atof(e); if (v > 0.0f) Cprim = v; }
-  std::vector<float> cost((size_t)nn * 7);
+  double Cnode = 1.0, Cprim = 0.3;
+  if (const char* e = getenv("PT_BVH_CPRIM")) { const double v = atof(e); if (v > 0.0) Cprim = v; }
+  std::vector<double> cost((size_t)nn * 7);
   std::vector<uint8_t> dec((size_t)nn * 7);
   std::vector<uint8_t> isplit(nn, 0);
   for (uint32_t idx = nn; idx-- > 0;) {
     const Node2& nd = n2[idx];
-    const float A = half_area(nd.lo, nd.hi);
-    float* c = &cost[(size_t)idx * 7];
+    const double A = half_area(nd.lo, nd.hi);
+    double* c = &cost[(size_t)idx * 7];
     uint8_t* d = &dec[(size_t)idx * 7];
     if (nd.left == 0) {
-      for (int i = 0; i < 7; ++i) { c[i] = A * Cprim * (float)nd.count; d[i] = mk_dec(D_LEAF, 0, 0); }
+      for (int i = 0; i < 7; ++i) { c[i] = A * Cprim * (double)nd.count; d[i] = mk_dec(D_LEAF, 0, 0); }
       continue;
     }
-    const float* cl = &cost[(size_t)nd.left * 7];
-    const float* cr = &cost[(size_t)(nd.left + 1) * 7];
-    float cdist[9]; int ksplit[9];
+    const double* cl = &cost[(size_t)nd.left * 7];
+    const double* cr = &cost[(size_t)(nd.left + 1) * 7];
+    double cdist[9]; int ksplit[9];
     for (int j = 2; j <= 8; ++j) {
-      float best = FLT_MAX; int bk = 1;
+      double best = DBL_MAX; int bk = 1;
       for (int k = 1; k < j; ++k) {
         if (k > 7 || j - k > 7) continue;
-        float v = cl[k - 1] + cr[j - k - 1];
+        const double v = cl[k - 1] + cr[j - k - 1];
         if (v < best) { best = v; bk = k; }
       }
       cdist[j] = best; ksplit[j] = bk;
     }
-    const float cleaf = nd.count <= PT_BVH8_MAX_LEAF_TRIS ? A * Cprim * (float)nd.count : FLT_MAX;
-    const float cint = cdist[8] + A * Cnode;
+    const double cleaf = nd.count <= PT_BVH8_MAX_LEAF_TRIS ? A * Cprim * (double)nd.count : DBL_MAX;
+    const double cint = cdist[8] + A * Cnode;
     isplit[idx] = (uint8_t)ksplit[8];
     if (cleaf <= cint) { c[0] = cleaf; d[0] = mk_dec(D_LEAF, 0, 0); }
     else { c[0] = cint; d[0] = mk_dec(D_INTERNAL, 0, 0); }
@@ -296,7 +303,7 @@ void build_bvh8(const float* verts, uint32_t n, Bvh8& out, int num_threads) {
       else { c[i] = c[i - 1]; d[i] = d[i - 1]; }
     }
   }
-  out.sah_cost = cost[0];
+  out.sah_cost = (float)cost[0];
 
   // ---- emit 8-wide nodes breadth-first ----
   struct Work { uint32_t n2; uint32_t out; uint32_t depth; };

@@ -161,6 +161,37 @@ def test_edge_cases_empty_scene_axis_rays_degenerate_triangles(ctx, oracle):
     assert list(got["prim"][:3]) == [0, 1, 1]
 
 
+@pytest.mark.parametrize("name", ["nan_vertex", "inf_vertex", "many_nan", "far_vertex", "all_identical", "on_a_line", "tiny", "huge"])
+def test_pathological_vertices_do_not_break_builder_or_kernels(ctx, oracle, name):
+    """NaN / Inf vertices make a triangle inactive (it can never be hit) without disturbing the others; one vertex at
+    1e30 must not poison the SAH costs; degenerate and extreme-scale scenes still build. Checked against the oracle's
+    brute-force loop over all triangles."""
+    base = scenes.random_triangle_soup(3, 3000)
+    v, i = base.meshes[0]
+    v = v.copy()
+    edit = {
+        "nan_vertex": lambda: v["pos"].__setitem__((7, 1), np.nan),
+        "inf_vertex": lambda: v["pos"].__setitem__((11, 0), np.inf),
+        "many_nan": lambda: v["pos"].__setitem__((slice(0, 100), 2), np.nan),
+        "far_vertex": lambda: v["pos"].__setitem__((5, slice(None)), 1e30),
+        "all_identical": lambda: v["pos"].__setitem__(slice(None), 1.0),
+        "on_a_line": lambda: v["pos"].__setitem__((slice(None), slice(1, 3)), 0.0),
+        "tiny": lambda: v["pos"].__imul__(np.float32(1e-20)),
+        "huge": lambda: v["pos"].__imul__(np.float32(1e18)),
+    }[name]
+    edit()
+    sc = SceneData([(v, i)], base.instances, base.materials)
+    ctx.scene_create(sc)
+    osc = oracle.scene(sc)
+    scale = {"tiny": 1e-20, "huge": 1e18}.get(name, 1.0)
+    rays = random_rays(1, 4000, [-10 * scale] * 3, [10 * scale] * 3, tmax=1e30)
+    got = ctx.trace_rays(rays)
+    ref = osc.trace_rays(rays, brute=True)
+    assert np.array_equal(got["prim"], ref["prim"])
+    if name in ("nan_vertex", "inf_vertex", "many_nan", "far_vertex"):
+        assert (ref["prim"] != api.PT_MISS).mean() > 0.05      # the healthy triangles are still found
+
+
 def test_non_finite_rays_miss_quickly(ctx, oracle):
     """NaN/Inf rays (the shading can produce them: Q7 0/0, normalize(0)) are misses and must not walk the whole BVH."""
     import time
