@@ -33,6 +33,7 @@ int flatten_scene(const PtMeshDesc* meshes, uint32_t num_meshes, const PtInstanc
   // every index must address a vertex of its mesh (checked once per mesh)
   for (uint32_t mi = 0; mi < num_meshes; ++mi) {
     const PtMeshDesc& m = meshes[mi];
+    if ((m.num_vertices && !m.vertices) || (m.num_triangles && !m.indices)) { err = "pt_scene_create: mesh " + std::to_string(mi) + " has null data"; return PT_ERR_INVALID_ARG; }
     for (size_t k = 0; k < (size_t)m.num_triangles * 3; ++k)
       if (m.indices[k] >= m.num_vertices) { err = "pt_scene_create: mesh " + std::to_string(mi) + " has an index beyond its vertex count"; return PT_ERR_INVALID_ARG; }
   }
