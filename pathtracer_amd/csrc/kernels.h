@@ -17,6 +17,7 @@ struct DeviceScene {
   const float4* materials = nullptr;   // emission.xyz, rgba8 bits
   const float4* instance_mat4 = nullptr; // materials[instance_material[i]] per instance
   const float4* instance_ext = nullptr;  // material extension per instance (roughness, metallic, pattern scale, pattern | ggx << 8); null = none
+  float scene_mag = 0.0f;              // largest |coordinate| of the active triangles (overflow guard of the box test)
   uint32_t stack_entries = 0;          // stack entries per lane the traversal may need (2 per BVH level + 2)
   uint2* spill = nullptr;              // global spill region of the per-lane stacks: [wave][entry][lane]
 };
@@ -52,6 +53,8 @@ struct WavefrontBuffers {
 };
 
 #define PT_SKYVIEW_TEXELS (256 * 256)   // PT_SKYVIEW_W x PT_SKYVIEW_H of sky_device.h
+
+#define PT_EXTEND_MAX_LDS_ENTRIES 64u   // stack + deferred-queue entries per lane kept in LDS (128 KB per block at most)
 
 struct LaunchCfg {
   int num_cus = 256;

@@ -131,7 +131,7 @@ __global__ void __launch_bounds__(256) k_extend(const uint4* __restrict__ nodes,
                                                 float4* __restrict__ hits, const uint32_t* __restrict__ count_ptr,
                                                 uint32_t* __restrict__ work_cursor, unsigned long long* __restrict__ stats,
                                                 uint32_t lds_entries, uint32_t spill_entries, uint2* __restrict__ spill, uint32_t stride, uint32_t fetch_min,
-                                                uint32_t postpone_pct, uint32_t dq_entries, uint32_t any_hit) {
+                                                uint32_t postpone_pct, uint32_t dq_entries, uint32_t any_hit, float scene_mag) {
   // any_hit (wave-uniform): a ray ends at the first accepted intersection (occlusion queries: Ao.hlsl's ClosestHitAo
   // only reports that something was hit). Only "prim != miss" is then defined in the hit record.
   extern __shared__ uint2 s_stack[];
@@ -187,7 +187,7 @@ __global__ void __launch_bounds__(256) k_extend(const uint4* __restrict__ nodes,
           // drop NaNs, so its box tests would all pass and it would walk the whole BVH: report the miss right away.
           const float chk = (r.ox + r.oy + r.oz) + (r.dx + r.dy + r.dz);
           if (isfinite(chk)) {
-            tr.init(r);
+            tr.init(r, scene_mag);
             busy = true;
           } else {
             hits[ray_i] = make_float4(-1.0f, 0.0f, 0.0f, __uint_as_float(0xFFFFFFFFu));
@@ -711,7 +711,9 @@ int extend_occupancy_blocks(uint32_t lds_entries_total, bool defer) {
 static size_t g_extend_lds_granted = 0;
 void launch_extend(const DeviceScene& sc, const float4* ray_o, const float4* ray_d, uint32_t stride, float4* hits, const uint32_t* count,
                    uint32_t* work_cursor, unsigned long long* stats, bool count_traversal, bool any_hit, const LaunchCfg& cfg, hipStream_t s) {
-  const uint32_t lds_entries = sc.stack_entries < cfg.lds_stack_entries ? sc.stack_entries : cfg.lds_stack_entries;
+  uint32_t lds_entries = sc.stack_entries < cfg.lds_stack_entries ? sc.stack_entries : cfg.lds_stack_entries;
+  if (lds_entries + cfg.defer_entries > PT_EXTEND_MAX_LDS_ENTRIES)   // 2 KB of LDS per entry and block: stay within one CU's LDS
+    lds_entries = PT_EXTEND_MAX_LDS_ENTRIES - cfg.defer_entries;     // the rest of the stack goes to the spill region
   const uint32_t spill_entries = sc.stack_entries - lds_entries;
   const uint32_t dq = cfg.defer_entries;
   const size_t lds = extend_lds_bytes(lds_entries + dq);
@@ -724,7 +726,7 @@ void launch_extend(const DeviceScene& sc, const float4* ray_o, const float4* ray
   }
 #define PT_LAUNCH_EXTEND(C, D)                                                                                              \
   hipLaunchKernelGGL((k_extend<C, D>), dim3(cfg.extend_blocks), dim3(256), lds, s, sc.nodes, sc.tris, ray_o, ray_d, hits, count, \
-                     work_cursor, stats, lds_entries, spill_entries, sc.spill, stride, cfg.fetch_min, cfg.postpone_pct, dq, any_hit ? 1u : 0u)
+                     work_cursor, stats, lds_entries, spill_entries, sc.spill, stride, cfg.fetch_min, cfg.postpone_pct, dq, any_hit ? 1u : 0u, sc.scene_mag)
   if (dq > 0) {
     if (count_traversal) PT_LAUNCH_EXTEND(true, true); else PT_LAUNCH_EXTEND(false, true);
   } else {

@@ -218,7 +218,7 @@ int ensure_tmp(pt_ctx* ctx, uint64_t rays) {
 int extend_grid(pt_ctx* ctx) {
   int per_cu = ctx->cfg.extend_blocks_per_cu;
   if (per_cu <= 0) {
-    const uint32_t lds_entries = std::min(ctx->ds.stack_entries, ctx->cfg.lds_stack_entries) + ctx->cfg.defer_entries;
+    const uint32_t lds_entries = std::min<uint32_t>(std::min(ctx->ds.stack_entries, ctx->cfg.lds_stack_entries) + ctx->cfg.defer_entries, PT_EXTEND_MAX_LDS_ENTRIES);
     per_cu = std::max(1, std::min(8, extend_occupancy_blocks(lds_entries, ctx->cfg.defer_entries > 0)));
   }
   return ctx->cfg.num_cus * per_cu;
@@ -444,6 +444,7 @@ int pt_scene_create(pt_ctx* ctx, const PtMeshDesc* meshes, uint32_t num_meshes, 
   ctx->ds.instance_material = d_im;
   ctx->ds.materials = d_mat;
   ctx->ds.instance_mat4 = d_imat;
+  for (int a = 0; a < 3; ++a) ctx->ds.scene_mag = std::max(ctx->ds.scene_mag, std::max(std::fabs(bvh.lo[a]), std::fabs(bvh.hi[a])));
   ctx->ds.stack_entries = 2 * bvh.max_depth + 2;   // <=1 sibling group + <=1 postponed triangle group per level
   if (bvh.max_depth > 62)
     return ctx->fail(PT_ERR_UNSUPPORTED, "BVH deeper than the traversal stack supports (" + std::to_string(bvh.max_depth) + " levels)");

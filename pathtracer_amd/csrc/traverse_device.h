@@ -115,8 +115,9 @@ struct Traverser {
   uint2 ng;           // pending node group: x = child_base, y = hit bits (top 8, by octant priority) | imask
   uint2 tg;           // pending triangle group: x = tri_base, y = triangle bits (low 24)
   int sp;
+  bool risky;         // the fast slab form could overflow for this ray (see node_step)
 
-  __device__ __forceinline__ void init(const TraceRay& r) {
+  __device__ __forceinline__ void init(const TraceRay& r, float scene_mag) {
     ray = r;
     best.t = r.tmax; best.u = 0.0f; best.v = 0.0f; best.prim = 0xFFFFFFFFu;
     tt.init(r);
@@ -126,33 +127,18 @@ struct Traverser {
     ng = make_uint2(0u, 0x80000000u);  // root: one pending internal "child" at priority 7 of a group with base 0
     tg = make_uint2(0u, 0u);
     sp = 0;
+    const float reach = fmaxf(scene_mag, fmaxf(fabsf(r.ox), fmaxf(fabsf(r.oy), fabsf(r.oz))));
+    risky = !(reach * fmaxf(fabsf(idx), fmaxf(fabsf(idy), fabsf(idz))) < 1e36f);
   }
 
   __device__ __forceinline__ bool has_node_work() const { return ng.y > 0x00FFFFFFu; }
 
-  // Pops the nearest pending internal child, fetches its 80-byte node (5 x 128-bit loads) and intersects the 8
-  // quantised child boxes.
-  __device__ __forceinline__ void node_step(const uint4* __restrict__ nodes, const LaneStack& stk) {
-    const uint32_t hits = ng.y;
-    const int b = 31 - __clz((int)hits);
-    ng.y &= ~(1u << b);
-    if (ng.y > 0x00FFFFFFu) { stk.put(sp, ng); ++sp; }
-    const uint32_t slot = ((uint32_t)b - 24u) ^ oct;
-    const uint32_t rel = __popc(hits & ~(0xFFFFFFFFu << slot));
-    const uint4* np = nodes + (size_t)(ng.x + rel) * PT_NODE_STRIDE_U4;
-    const uint4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3], n4 = np[4];
-
-    const uint32_t e = n0.w;
-    const float ax = __uint_as_float((e & 0xffu) << 23) * idx;
-    const float ay = __uint_as_float(((e >> 8) & 0xffu) << 23) * idy;
-    const float az = __uint_as_float(((e >> 16) & 0xffu) << 23) * idz;
-    const float bx = (__uint_as_float(n0.x) - ray.ox) * idx;
-    const float by = (__uint_as_float(n0.y) - ray.oy) * idy;
-    const float bz = (__uint_as_float(n0.z) - ray.oz) * idz;
-    const bool negx = (oct & 1u) != 0u, negy = (oct & 2u) != 0u, negz = (oct & 4u) != 0u;
-    const uint32_t oct4 = oct * 0x01010101u;
-
-    uint32_t hitmask = 0u;
+  // Slab tests of the 8 quantised child boxes of one node. SAFE: (ax,bx) = (2^e, p - o), scaled by 1/d afterwards;
+  // otherwise (ax,bx) = (2^e / d, (p - o) / d).
+  template <bool SAFE>
+  __device__ __forceinline__ void child_tests(const uint4& n1, const uint4& n2, const uint4& n3, const uint4& n4, float ax, float ay,
+                                              float az, float bx, float by, float bz, bool negx, bool negy, bool negz,
+                                              uint32_t oct4, uint32_t& hitmask) const {
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const uint32_t meta4 = h ? n1.w : n1.z;
@@ -167,12 +153,13 @@ struct Traverser {
       const uint32_t child_bits4 = (meta4 >> 5) & 0x07070707u;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const float tnx = __builtin_fmaf((float)((nx >> (8 * j)) & 0xffu), ax, bx);
-        const float tny = __builtin_fmaf((float)((ny >> (8 * j)) & 0xffu), ay, by);
-        const float tnz = __builtin_fmaf((float)((nz >> (8 * j)) & 0xffu), az, bz);
-        const float tfx = __builtin_fmaf((float)((fx >> (8 * j)) & 0xffu), ax, bx);
-        const float tfy = __builtin_fmaf((float)((fy >> (8 * j)) & 0xffu), ay, by);
-        const float tfz = __builtin_fmaf((float)((fz >> (8 * j)) & 0xffu), az, bz);
+        float tnx = __builtin_fmaf((float)((nx >> (8 * j)) & 0xffu), ax, bx);
+        float tny = __builtin_fmaf((float)((ny >> (8 * j)) & 0xffu), ay, by);
+        float tnz = __builtin_fmaf((float)((nz >> (8 * j)) & 0xffu), az, bz);
+        float tfx = __builtin_fmaf((float)((fx >> (8 * j)) & 0xffu), ax, bx);
+        float tfy = __builtin_fmaf((float)((fy >> (8 * j)) & 0xffu), ay, by);
+        float tfz = __builtin_fmaf((float)((fz >> (8 * j)) & 0xffu), az, bz);
+        if (SAFE) { tnx *= idx; tny *= idy; tnz *= idz; tfx *= idx; tfy *= idy; tfz *= idz; }
         const float tn = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, ray.tmin));
         const float tf = fminf(fminf(tfx, tfy), fminf(tfz, best.t));
         // conservative: widen by ~8 ulp so fp32 rounding of the slab arithmetic can never cull a true hit
@@ -182,6 +169,36 @@ struct Traverser {
           hitmask |= cb << bi;
         }
       }
+    }
+  }
+
+  // Pops the nearest pending internal child, fetches its 80-byte node (5 x 128-bit loads) and intersects the 8
+  // quantised child boxes.
+  __device__ __forceinline__ void node_step(const uint4* __restrict__ nodes, const LaneStack& stk) {
+    const uint32_t hits = ng.y;
+    const int b = 31 - __clz((int)hits);
+    ng.y &= ~(1u << b);
+    if (ng.y > 0x00FFFFFFu) { stk.put(sp, ng); ++sp; }
+    const uint32_t slot = ((uint32_t)b - 24u) ^ oct;
+    const uint32_t rel = __popc(hits & ~(0xFFFFFFFFu << slot));
+    const uint4* np = nodes + (size_t)(ng.x + rel) * PT_NODE_STRIDE_U4;
+    const uint4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3], n4 = np[4];
+
+    const uint32_t e = n0.w;
+    const float sx = __uint_as_float((e & 0xffu) << 23), sy = __uint_as_float(((e >> 8) & 0xffu) << 23),
+                sz = __uint_as_float(((e >> 16) & 0xffu) << 23);
+    const float px = __uint_as_float(n0.x) - ray.ox, py = __uint_as_float(n0.y) - ray.oy, pz = __uint_as_float(n0.z) - ray.oz;
+    const bool negx = (oct & 1u) != 0u, negy = (oct & 2u) != 0u, negz = (oct & 4u) != 0u;
+    const uint32_t oct4 = oct * 0x01010101u;
+    uint32_t hitmask = 0u;
+    // Fast form: t = q * (2^e / d) + (p - o) / d, one FMA per plane. Its two terms can overflow fp32 although their sum
+    // is small (|scene coordinate| / |d| > ~1e37: astronomically large scenes, or near-axis-parallel rays in large
+    // ones); such rays (flagged once, at init) take the safe form t = (q * 2^e + (p - o)) / d, where only a genuinely
+    // huge distance overflows, with the right sign. The wave-level test keeps the safe form out of ordinary waves.
+    if (__ballot(risky) != 0ull && risky) {
+      child_tests<true>(n1, n2, n3, n4, sx, sy, sz, px, py, pz, negx, negy, negz, oct4, hitmask);
+    } else {
+      child_tests<false>(n1, n2, n3, n4, sx * idx, sy * idy, sz * idz, px * idx, py * idy, pz * idz, negx, negy, negz, oct4, hitmask);
     }
     ng.x = n1.x;
     ng.y = (hitmask & 0xFF000000u) | (e >> 24);

@@ -192,6 +192,47 @@ def test_pathological_vertices_do_not_break_builder_or_kernels(ctx, oracle, name
         assert (ref["prim"] != api.PT_MISS).mean() > 0.05      # the healthy triangles are still found
 
 
+def test_deep_hierarchy_with_every_stack_configuration(ctx, oracle):
+    """Geometrically growing triangles give a hierarchy far deeper than the LDS part of the traversal stack: the LDS
+    clamp, the spill region and the deferred queue must all give the brute-force answer."""
+    n = 3000
+    k = np.arange(n, dtype=np.float64)
+    s = 1.028 ** k
+    v = np.zeros(3 * n, dtype=api.VERTEX_DTYPE)
+    pos = np.zeros((n, 3, 3))
+    pos[:, 0] = np.stack([s, 0 * s, 0.001 * k], axis=1)
+    pos[:, 1] = np.stack([-s, s, 0.001 * k], axis=1)
+    pos[:, 2] = np.stack([-s, -s, 0.001 * k], axis=1)
+    v["pos"] = pos.reshape(-1, 3).astype(np.float32)
+    v["normal"] = (0, 0, 1)
+    idx = np.arange(3 * n, dtype=np.uint32)
+    sc = SceneData([(v, idx)], [(0, 0, None)], [((0, 0, 0), (0.5, 0.5, 0.5, 1))])
+    ctx.scene_create(sc)
+    osc = oracle.scene(sc)
+    depth = ctx.scene_info().bvh_max_depth
+    assert depth >= 24, depth         # 2*depth+2 stack entries + 16 deferred: beyond what the kernel keeps in LDS
+    rng = np.random.default_rng(2)
+    rays = np.zeros(6000, dtype=api.RAY_DTYPE)
+    r = 1.028 ** rng.uniform(0, n, 6000)
+    ang = rng.uniform(0, 2 * np.pi, 6000)
+    rays["origin"] = np.stack([0.3 * r * np.cos(ang), 0.3 * r * np.sin(ang), np.full(6000, -5.0)], axis=1).astype(np.float32)
+    d = np.stack([rng.normal(0, 0.2, 6000), rng.normal(0, 0.2, 6000), np.ones(6000)], axis=1)
+    rays["dir"] = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    rays["tmin"], rays["tmax"] = 0.0, 1e30
+    ref = osc.trace_rays(rays, brute=True)
+    assert (ref["prim"] != api.PT_MISS).mean() > 0.5
+    try:
+        for lds, defer in ((8, 4), (128, 16), (1, 0), (2, 1), (64, 0)):
+            ctx.set_option(api.PT_OPT_EXTEND_LDS_STACK, lds)
+            ctx.set_option(api.PT_OPT_EXTEND_DEFER, defer)
+            got = ctx.trace_rays(rays)
+            assert np.array_equal(got["prim"], ref["prim"]), (lds, defer)
+            assert np.array_equal(got["t"].view(np.uint32), ref["t"].view(np.uint32)), (lds, defer)
+    finally:
+        ctx.set_option(api.PT_OPT_EXTEND_LDS_STACK, 8)
+        ctx.set_option(api.PT_OPT_EXTEND_DEFER, 4)
+
+
 def test_non_finite_rays_miss_quickly(ctx, oracle):
     """NaN/Inf rays (the shading can produce them: Q7 0/0, normalize(0)) are misses and must not walk the whole BVH."""
     import time
