@@ -233,6 +233,41 @@ def test_deep_hierarchy_with_every_stack_configuration(ctx, oracle):
         ctx.set_option(api.PT_OPT_EXTEND_DEFER, 4)
 
 
+def test_coincident_geometry_resolves_ties_to_the_lower_triangle_id(ctx, oracle):
+    """Three instances of the same mesh at the same place: every hit is an exact t tie between three triangles, and
+    closest-hit must report the lowest global id whatever order the traversal meets them in."""
+    base = scenes.random_triangle_soup(8, 2000)
+    sc = SceneData(base.meshes, [(0, 0, None), (0, 0, None), (0, 0, None)], base.materials)
+    ctx.scene_create(sc)
+    osc = oracle.scene(sc)
+    rays = random_rays(5, 30000, [-10] * 3, [10] * 3)
+    got, ref = ctx.trace_rays(rays), osc.trace_rays(rays, brute=True)
+    hit = ref["prim"] != api.PT_MISS
+    assert hit.mean() > 0.05
+    assert np.array_equal(got["prim"], ref["prim"])
+    assert (ref["prim"][hit] < 2000).all()                     # always the first instance's triangle
+    assert np.array_equal(got["t"].view(np.uint32), ref["t"].view(np.uint32))
+
+
+@pytest.mark.parametrize("w,h,spp", [(1, 1, 3), (67, 3, 5), (3, 129, 2), (65, 65, 1)])
+def test_odd_frame_sizes_match_oracle(ctx, cornell, w, h, spp):
+    """Frame sizes that are not multiples of the wave or block size, down to a single pixel."""
+    sc, osc = cornell
+    ctx.scene_create(sc)
+    c = cornell_consts(w, h, sky=False, fallback=100.0)
+    ctx.accum_reset(w, h)
+    ctx.stats_reset()
+    ctx.render(c, w, h, 2, spp)
+    img, n = ctx.accum_read_sum()
+    st = ctx.stats()
+    acc, ost, _ = osc.render(c, w, h, 2, spp)
+    assert n == spp and st.samples == w * h * spp
+    assert (st.rays, st.shaded_hits, st.sky_misses) == (ost["rays"], ost["shaded_hits"], ost["sky_misses"])
+    assert rel_mse(img, acc) < 1e-8
+    hits = ctx.primary_hits(c, w, h, 2)
+    assert np.array_equal(hits["prim"], osc.primary_hits(c, w, h, 2)["prim"])
+
+
 def test_non_finite_rays_miss_quickly(ctx, oracle):
     """NaN/Inf rays (the shading can produce them: Q7 0/0, normalize(0)) are misses and must not walk the whole BVH."""
     import time
