@@ -89,6 +89,29 @@ def test_sky_function_matches_oracle(ctx, oracle):
 
 
 # ---------------------------------------------------------------------------------------------- intersection
+@pytest.mark.parametrize("ylo,yhi", [(2e3, 9e4), (1.0e5, 1.2e5), (3e5, 5e6), (-5e3, -1.0)])
+def test_sky_function_at_extreme_altitudes_and_sun_angles(ctx, oracle, ylo, yhi):
+    """SampleSkyLuminance away from the ground-level inputs of the fixture: inside the upper atmosphere, just above
+    its top (MoveToTopAtmosphere, sky/Common.hlsl:320-339), from orbit and from below the surface (where the reference
+    arithmetic produces NaNs: the NaN pattern must be the same), with the sun high, below the horizon and on it."""
+    atm = oracle.earth_atmosphere()
+    ctx.sky_set(atm)
+    lut = oracle.transmittance_lut(atm)
+    rng = np.random.default_rng(0)
+    n = 8000
+    d = rng.normal(size=(n, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    pos = np.stack([rng.uniform(-1e4, 1e4, n), rng.uniform(ylo, yhi, n), rng.uniform(-1e4, 1e4, n)], axis=1)
+    rows = np.concatenate([pos, d], axis=1).astype(np.float32)
+    for sun in ((0.3, 0.8, 0.52), (0.0, -0.2, 0.98), (1.0, 0.0, 0.0)):
+        c = lookat_consts(64, 64, scenes.ATRIUM_CAM, sun_dir=sun)
+        g = ctx.debug_eval(api.PT_FN_SKY, rows, c).astype(np.float64)
+        o = oracle.eval(api.PT_FN_SKY, rows, consts=c, lut=lut).astype(np.float64)
+        fo, fg = np.isfinite(o).all(1), np.isfinite(g).all(1)
+        assert np.array_equal(fo, fg), sun
+        assert np.abs(g[fo] - o[fo]).max() <= 1e-4 * max(np.abs(o[fo]).max(), 1e-12), sun
+
+
 def test_cornell_primary_hits_bit_identical(ctx, cornell):
     sc, osc = cornell
     for (w, h, sample) in ((64, 64, 0), (512, 512, 0), (512, 512, 63), (33, 17, 5), (1, 1, 0)):
