@@ -188,7 +188,8 @@ enum {
   PT_OPT_TIME_KERNELS = 2,    /* 0/1: bracket kernels with HIP events (fills extend_ms/render_ms) */
   PT_OPT_SAMPLES_PER_BATCH = 3, /* samples per pixel kept in flight per wavefront batch (0 = auto) */
   PT_OPT_SKY_MODE = 4,        /* 0 = ray-march on every miss (reference, SampleSky.hlsl:7-47); 1 = 256x256 direction LUT built per pt_render
-                                 for the camera position (extension after sky/compute_skyView_lut.hlsl; image relMSE vs mode 0 < 1e-4) */
+                                 for the camera position (extension after sky/compute_skyView_lut.hlsl; image relMSE vs mode 0 < 1e-4;
+                                 cameras above 50 km of altitude are marched as in mode 0) */
   PT_OPT_EXTEND_FETCH_MIN = 5,     /* tuning: refill idle lanes of a wave once this many (1..64) are idle */
   PT_OPT_EXTEND_POSTPONE_PCT = 6,  /* tuning: postpone triangle tests while < this % of busy lanes have any (0 = never) */
   PT_OPT_EXTEND_BLOCKS_PER_CU = 7, /* tuning: persistent grid = CUs x this (0 = occupancy query) */

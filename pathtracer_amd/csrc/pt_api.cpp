@@ -224,6 +224,15 @@ int extend_grid(pt_ctx* ctx) {
   return ctx->cfg.num_cus * per_cu;
 }
 
+// The direction LUT of sky mode 1 is within relMSE 1e-4 of the marched sky for cameras up to ~50 km of altitude
+// (tools/exp_skyview_alt.py); higher up its horizon-split parametrisation loses accuracy, so those renders march.
+bool skyview_valid_for(const PtRtConsts& c) {
+  const double R = c.mySkyConsts.myAtmosphere.BottomRadius;
+  const double x = c.myCameraPos[0], y = (double)c.myCameraPos[1] + R, z = c.myCameraPos[2];
+  const double altitude = std::sqrt(x * x + y * y + z * z) - R;
+  return std::isfinite(altitude) && altitude <= 5.0e4;
+}
+
 int ensure_ao(pt_ctx* ctx, uint64_t rays) {
   if (ctx->ao_capacity >= rays) return PT_OK;
   PT_HIP(hipStreamSynchronize(ctx->stream));
@@ -647,7 +656,7 @@ int pt_render(pt_ctx* ctx, const PtRtConsts* consts, uint32_t width, uint32_t he
     PT_HIP(hipEventRecord(rev.first, ctx->stream));
   }
   const uint32_t bounces = consts->myMaxRecursionDepth + 1;  // inclusive loop bound (PathTracing.hlsl:68)
-  const bool use_skyview = ctx->sky_mode == 1 && consts->mySampleSky;
+  const bool use_skyview = ctx->sky_mode == 1 && consts->mySampleSky && skyview_valid_for(*consts);
   if (use_skyview) launch_skyview_lut(*consts, ctx->lut, ctx->skyview, ctx->stream);   // 64 Ki texels, a few microseconds
   for (uint32_t done = 0; done < num_samples;) {
     const uint32_t k = (uint32_t)std::min<uint64_t>(spb, num_samples - done);
@@ -709,7 +718,7 @@ int pt_render_ao(pt_ctx* ctx, const PtRtConsts* consts, uint32_t width, uint32_t
     rev = get_event_pair(ctx);
     PT_HIP(hipEventRecord(rev.first, ctx->stream));
   }
-  const bool use_skyview = ctx->sky_mode == 1 && consts->mySampleSky;
+  const bool use_skyview = ctx->sky_mode == 1 && consts->mySampleSky && skyview_valid_for(*consts);
   if (use_skyview) launch_skyview_lut(*consts, ctx->lut, ctx->skyview, ctx->stream);
   for (uint32_t s = 0; s < num_samples; ++s) {   // one reference frame (1 primary + <=16 AO rays per pixel) per batch
     PT_HIP(hipMemsetAsync(ctx->wb.counters, 0, CTR_WORDS * sizeof(uint32_t), ctx->stream));
