@@ -794,6 +794,48 @@ def test_full_size_properties_1080p(ctx, oracle):
 
 
 # ---------------------------------------------------------------------------------------------- API behaviour
+def test_api_call_sequences_with_reallocation(oracle):
+    """One context driven through scene replacement, target resizes (growing and shrinking wavefront state), both
+    pipelines, both lanes and option changes; every stage is checked against the oracle."""
+    from pathtracer_amd.context import Context
+    cx = Context(0)
+    try:
+        atm = oracle.earth_atmosphere()
+        cx.sky_set(atm)
+        olut = oracle.transmittance_lut(atm)
+        cornell, atrium = scenes.cornell_box(), scenes.atrium(1)
+        ocornell, oatrium = oracle.scene(cornell), oracle.scene(atrium)
+
+        def check(scene_o, c, w, h, first, spp, ao=False):
+            cx.accum_reset(w, h)
+            (cx.render_ao if ao else cx.render)(c, w, h, first, spp)
+            img = cx.accum_read_sum()[0]
+            ref = (scene_o.render_ao(c, w, h, first, spp, lut=olut)[0] if ao else scene_o.render(c, w, h, first, spp, lut=olut)[0])
+            assert rel_mse(img, ref) < 1e-4, (w, h, spp, ao, rel_mse(img, ref))      # the north-star bar; typically 1e-8..1e-6
+
+        cx.scene_create(cornell)
+        check(ocornell, cornell_consts(64, 64), 64, 64, 0, 2)
+        cx.scene_create(atrium)                                   # replaces the scene (new BVH, new spill regions)
+        cx.set_option(api.PT_OPT_PIPELINE, 1)
+        check(oatrium, lookat_consts(100, 60, scenes.ATRIUM_CAM), 100, 60, 7, 5)      # grows both lanes
+        check(oatrium, lookat_consts(30, 20, scenes.ATRIUM_CAM), 30, 20, 0, 3)        # smaller frame, same buffers
+        cx.set_option(api.PT_OPT_PIPELINE, 0)
+        cx.set_option(api.PT_OPT_SAMPLES_PER_BATCH, 2)
+        check(oatrium, lookat_consts(120, 70, scenes.ATRIUM_CAM), 120, 70, 1, 5)      # batches of 2, 2, 1
+        cx.set_option(api.PT_OPT_SAMPLES_PER_BATCH, 0)
+        cx.scene_create(cornell)
+        c = cornell_consts(48, 48, sky=True)
+        c.myAoDistance = 30.0
+        check(ocornell, c, 48, 48, 3, 2, ao=True)
+        cx.sky_set(atm)                                           # recomputing the LUT is idempotent
+        assert np.array_equal(cx.sky_lut_read(), olut)
+        hits = cx.primary_hits(cornell_consts(200, 100), 200, 100, 1)     # larger than any wavefront state so far
+        assert np.array_equal(hits["prim"], ocornell.primary_hits(cornell_consts(200, 100), 200, 100, 1)["prim"])
+        check(ocornell, cornell_consts(64, 64), 64, 64, 0, 2)
+    finally:
+        cx.close()
+
+
 def test_error_codes(oracle):
     from pathtracer_amd import Context
     c2 = Context(0)
