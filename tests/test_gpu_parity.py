@@ -612,6 +612,25 @@ def test_pipeline_lanes_are_bit_identical_to_single_lane(ctx, oracle):
     assert out[0][1] == 14
 
 
+def test_batch_size_never_changes_the_image(ctx, oracle):
+    """PT_OPT_SAMPLES_PER_BATCH only groups samples into wavefront batches: the RNG is keyed on the sample index and
+    the resolve adds in sample order, so the target is bit-identical for any batch size."""
+    ctx.scene_create(scenes.atrium(1))
+    ctx.sky_set(oracle.earth_atmosphere())
+    w, h = 120, 70
+    c = lookat_consts(w, h, scenes.ATRIUM_CAM)
+    imgs = []
+    try:
+        for spb in (0, 1, 2, 3):
+            ctx.set_option(api.PT_OPT_SAMPLES_PER_BATCH, spb)
+            ctx.accum_reset(w, h)
+            ctx.render(c, w, h, 1, 5)
+            imgs.append(ctx.accum_read_sum()[0])
+    finally:
+        ctx.set_option(api.PT_OPT_SAMPLES_PER_BATCH, 0)
+    assert all(np.array_equal(imgs[0], im) for im in imgs[1:])
+
+
 def test_pt_reduce_adds_targets_of_several_contexts(ctx, cornell):
     """pt_reduce (single-process multi-GPU): two more contexts on this device stand in for two more GPUs."""
     from pathtracer_amd.context import Context, reduce_contexts
