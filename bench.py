@@ -24,6 +24,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+VALU_PEAK_GINSTR = 1228.8      # wave64 VALU instructions/s: 256 CUs x 4 SIMD32 x 2.4 GHz / 2 cycles (MI355X_MICROARCH.md)
 NODE_BYTES, TRI_BYTES, RAY_IO_BYTES = 80, 48, 48   # B_ray = 80*N_node + 48*N_tri + 48
 DEF_DEFER, DEF_POSTPONE = 4, 50                   # the library defaults (csrc/kernels.h LaunchCfg)
 
@@ -194,18 +195,30 @@ def main():
         # (3) measured memory-side traffic of the same kernel: PMC counters cannot be read from inside this process, so the
         #     figure comes from the committed rocprofv3 --pmc passes of this command (tools/prof_pmc.sh ->
         #     tools/pmc_traffic.py -> profiles/r01/pmc_traffic.json), matched on workload, size and batch; null otherwise.
-        traffic, traffic_note = None, "no PMC profile committed for this workload/size"
+        traffic, traffic_note, valu = None, "no PMC profile committed for this workload/size", None
         try:
             with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01", "pmc_traffic.json")) as f:
                 for e in json.load(f):
                     if (e["workload"], e["width"], e["height"], e["spp_per_step"], e["depth"]) == (args.workload, W, H, SPP, depth):
                         traffic = e["extend_bytes_per_launch"]
                         traffic_note = e["note"]
+                        if e.get("extend_valu_wave_instr_per_launch"):
+                            valu = {"wave_instr_per_launch": e["extend_valu_wave_instr_per_launch"],
+                                    "lanes_active_per_instr": e.get("extend_lanes_active_per_valu_instr")}
         except (OSError, ValueError, KeyError):
             pass
         roofline = {
             "bound": "hbm", "kernel": "k_extend", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_note": traffic_note,
+            # measured fabric-side bandwidth of the kernel (traffic / launch time) as a fraction of the same peak
+            "traffic_frac": (round(traffic / (se.extend_ms / max(1, se.extend_launches) * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
+                             if traffic else None),
+            # secondary bound (north star: "fraction of HBM/VALU roofline"): VALU issue. Instruction count per launch from
+            # the same PMC profile; peak = 256 CUs x 4 SIMDs x 2.4 GHz / 2 cycles per wave64 instruction.
+            "valu": ({**valu, "achieved_ginstr_per_s": round(valu["wave_instr_per_launch"] / (se.extend_ms / max(1, se.extend_launches) * 1e-3) / 1e9, 1),
+                      "peak_ginstr_per_s": VALU_PEAK_GINSTR,
+                      "frac": round(valu["wave_instr_per_launch"] / (se.extend_ms / max(1, se.extend_launches) * 1e-3) / 1e9 / VALU_PEAK_GINSTR, 4)}
+                     if valu else None),
             "nodes_per_ray": round(nodes_per_ray, 3), "tris_per_ray": round(tris_per_ray, 3),
             "shipped_schedule": {"nodes_per_ray": round(ship.nodes_visited / max(1, ship.rays), 3),
                                  "tris_per_ray": round(ship.tris_tested / max(1, ship.rays), 3),

@@ -21,10 +21,14 @@ for k in acc:
     n = calls[k]["FETCH_SIZE"]
     fetch_kb = acc[k]["FETCH_SIZE"] / n
     write_kb = acc[k].get("WRITE_SIZE", 0.0) / max(1, calls[k].get("WRITE_SIZE", 1))
-    out["kernels"][k] = {"launches_profiled": n, "fetch_size_kb_per_launch_raw": round(fetch_kb, 1), "write_size_kb_per_launch_raw": round(write_kb, 1),
+    valu = acc[k].get("SQ_INSTS_VALU", 0.0) / max(1, calls[k].get("SQ_INSTS_VALU", 1))
+    lanes = acc[k].get("SQ_THREAD_CYCLES_VALU", 0.0) / max(1.0, acc[k].get("SQ_ACTIVE_INST_VALU", 1.0))
+    out["kernels"][k] = {"valu_wave_instr_per_launch": round(valu), "lanes_active_per_valu_instr": round(lanes, 2), "launches_profiled": n, "fetch_size_kb_per_launch_raw": round(fetch_kb, 1), "write_size_kb_per_launch_raw": round(write_kb, 1),
                          "bytes_per_launch_corrected": round((2.0 * fetch_kb + write_kb) * 1024.0)}
 e = out["kernels"].get("pt::k_extend")
 out["extend_bytes_per_launch"] = e["bytes_per_launch_corrected"] if e else None
+out["extend_valu_wave_instr_per_launch"] = e["valu_wave_instr_per_launch"] if e else None
+out["extend_lanes_active_per_valu_instr"] = e["lanes_active_per_valu_instr"] if e else None
 out["note"] = ("rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE (separate passes), mean over the k_extend launches of bench.py --steps 2; "
                "bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024, the gfx950 doubling of FETCH_SIZE applied although the BVH gathers are "
                "not the calibrated streaming pattern; fabric-side, Infinity-Cache hits included")
