@@ -4,7 +4,7 @@ The reference ships no tests or golden vectors, and cannot be 
 from the oracle itself: they freeze its behaviour (regression pins) and give the GPU tests inputs/outputs that do not
 need the oracle's BVH at run time. The exact integer KATs (rng_kat.json) were derived by hand from Random.hlsl:45-62,
 84-99 in SURVEY §8c and are only re-checked here, never re-generated.
-Run:  python tools/make_golden.py
+Run:  python tests/golden/make_golden.py
 """
 import json
 import os
@@ -12,7 +12,7 @@ import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from pathtracer_amd import api, scenes  # noqa: E402
 from tests import oracle_lib  # noqa: E402

@@ -231,7 +231,7 @@ def test_ao_pipeline_bvh_equals_brute_force_and_counts(oracle):
 
 
 def test_ao_and_russian_roulette_regression_pins(oracle):
-    """tests/golden/cornell_ao_64_4spp.* and cornell_rr_64_8spp_stats.json (tools/make_golden.py)."""
+    """tests/golden/cornell_ao_64_4spp.* and cornell_rr_64_8spp_stats.json (tests/golden/make_golden.py)."""
     sc = oracle.scene(scenes.cornell_box())
     c = cornell_consts(64, 64, sky=False, fallback=0.0)
     c.myAoDistance = 25.0
