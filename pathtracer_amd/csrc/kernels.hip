@@ -708,7 +708,6 @@ int extend_occupancy_blocks(uint32_t lds_entries_total, bool defer) {
   return nb;
 }
 
-static size_t g_extend_lds_granted = 0;
 void launch_extend(const DeviceScene& sc, const float4* ray_o, const float4* ray_d, uint32_t stride, float4* hits, const uint32_t* count,
                    uint32_t* work_cursor, unsigned long long* stats, bool count_traversal, bool any_hit, const LaunchCfg& cfg, hipStream_t s) {
   uint32_t lds_entries = sc.stack_entries < cfg.lds_stack_entries ? sc.stack_entries : cfg.lds_stack_entries;
@@ -717,12 +716,12 @@ void launch_extend(const DeviceScene& sc, const float4* ray_o, const float4* ray
   const uint32_t spill_entries = sc.stack_entries - lds_entries;
   const uint32_t dq = cfg.defer_entries;
   const size_t lds = extend_lds_bytes(lds_entries + dq);
-  if (lds > 64 * 1024 && lds > g_extend_lds_granted) {   // deep BVHs: opt in to more than the default dynamic-LDS limit
+  if (lds > 64 * 1024) {   // deep BVHs: opt in to more than the default dynamic-LDS limit. The attribute belongs to the CURRENT
+                           // device (one process may drive several, pt_reduce), so it is set on every such launch: no cached flag.
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_extend<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_extend<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_extend<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_extend<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    g_extend_lds_granted = lds;
   }
 #define PT_LAUNCH_EXTEND(C, D)                                                                                              \
   hipLaunchKernelGGL((k_extend<C, D>), dim3(cfg.extend_blocks), dim3(256), lds, s, sc.nodes, sc.tris, ray_o, ray_d, hits, count, \

@@ -203,9 +203,6 @@ int ensure_tmp(pt_ctx* ctx, uint64_t rays) {
   PT_HIP(hipStreamSynchronize(ctx->stream));
   if (ctx->tmp_rays) (void)hipFree(ctx->tmp_rays);
   if (ctx->tmp_hits) (void)hipFree(ctx->tmp_hits);
-  if (ctx->ao_o) (void)hipFree(ctx->ao_o);
-  if (ctx->ao_d) (void)hipFree(ctx->ao_d);
-  if (ctx->ao_hits) (void)hipFree(ctx->ao_hits);
   ctx->tmp_rays = nullptr; ctx->tmp_hits = nullptr; ctx->tmp_capacity = 0;
   int rc;
   if ((rc = dev_alloc(ctx, &ctx->tmp_rays, rays * 2, nullptr))) return rc;
@@ -325,6 +322,9 @@ int pt_destroy(pt_ctx* ctx) {
   if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
   if (ctx->tmp_rays) (void)hipFree(ctx->tmp_rays);
   if (ctx->tmp_hits) (void)hipFree(ctx->tmp_hits);
+  if (ctx->ao_o) (void)hipFree(ctx->ao_o);     // the AO ray buffers belong to ensure_ao alone
+  if (ctx->ao_d) (void)hipFree(ctx->ao_d);
+  if (ctx->ao_hits) (void)hipFree(ctx->ao_hits);
   if (ctx->lut) (void)hipFree(ctx->lut);
   if (ctx->skyview) (void)hipFree(ctx->skyview);
   if (ctx->accum && ctx->accum_owned) (void)hipFree(ctx->accum);

@@ -19,7 +19,8 @@ def partition_samples(total_samples, world_size, rank):
 
 def reduce_sum_to_root(accum, num_samples, group=None, root=0):
     """Sum the per-rank accumulation targets (tensor of W*H*4 floats, sum of samples) onto `root` and return
-    (accum, total_sample_count). One reduce + one tiny all-reduce of the counts."""
+    (accum, total_sample_count). One reduce + one tiny all-reduce of the counts. The collective runs on torch's
+    stream: call ctx.synchronize() first so every render queued on the ctx stream has landed in `accum`."""
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return accum, int(num_samples)
     cnt = torch.tensor([int(num_samples)], dtype=torch.int64, device=accum.device)
@@ -30,7 +31,8 @@ def reduce_sum_to_root(accum, num_samples, group=None, root=0):
 
 def gather_ordered_sum_to_root(accum, num_samples, group=None, root=0):
     """Bit-reproducible variant: gather every rank's target on root and add them in rank order, so the result does
-    not depend on RCCL's internal reduction order (fp32 addition is not associative)."""
+    not depend on RCCL's internal reduction order (fp32 addition is not associative). ctx.synchronize() must
+    precede it, as for reduce_sum_to_root."""
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return accum, int(num_samples)
     world = dist.get_world_size(group)
@@ -50,8 +52,10 @@ def gather_ordered_sum_to_root(accum, num_samples, group=None, root=0):
 
 
 def bind_torch_target(ctx, width, height, device):
-    """Allocate the accumulation target as a torch tensor (so RCCL can reduce it in place) and bind it to the ctx."""
-    t = torch.zeros(height * width * 4, dtype=torch.float32, device=device)
+    """Allocate the accumulation target as a torch tensor (so RCCL can reduce it in place) and bind it to the ctx.
+    torch.empty, not zeros: pt_accum_bind zeroes the target on the ctx stream, and a fill kernel on torch's current
+    stream would not be ordered against it."""
+    t = torch.empty(height * width * 4, dtype=torch.float32, device=device)
     ctx.accum_bind(t.data_ptr(), width, height)
     return t
 
@@ -75,7 +79,7 @@ def rank_partitions(world_size, rank):
 def render_virtual_partitions(ctx, consts, width, height, total_samples, world_size, rank, device, first_sample=0):
     """Render this rank's virtual partitions; returns a (len(rank_partitions), H*W*4) float32 tensor of block sums."""
     mine = rank_partitions(world_size, rank)
-    out = torch.zeros((len(mine), height * width * 4), dtype=torch.float32, device=device)
+    out = torch.empty((len(mine), height * width * 4), dtype=torch.float32, device=device)   # accum_bind zeroes each block
     for k, v in enumerate(mine):
         first, n = partition_samples(total_samples, VIRTUAL_PARTITIONS, v)
         ctx.accum_bind(out[k].data_ptr(), width, height)      # zeroes the block target

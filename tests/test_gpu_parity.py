@@ -215,9 +215,8 @@ def test_pathological_vertices_do_not_break_builder_or_kernels(ctx, oracle, name
         assert (ref["prim"] != api.PT_MISS).mean() > 0.05      # the healthy triangles are still found
 
 
-def test_deep_hierarchy_with_every_stack_configuration(ctx, oracle):
-    """Geometrically growing triangles give a hierarchy far deeper than the LDS part of the traversal stack: the LDS
-    clamp, the spill region and the deferred queue must all give the brute-force answer."""
+def deep_hierarchy_scene():
+    """Geometrically growing triangles: a hierarchy far deeper than the LDS part of the traversal stack, plus rays."""
     n = 3000
     k = np.arange(n, dtype=np.float64)
     s = 1.028 ** k
@@ -230,10 +229,6 @@ def test_deep_hierarchy_with_every_stack_configuration(ctx, oracle):
     v["normal"] = (0, 0, 1)
     idx = np.arange(3 * n, dtype=np.uint32)
     sc = SceneData([(v, idx)], [(0, 0, None)], [((0, 0, 0), (0.5, 0.5, 0.5, 1))])
-    ctx.scene_create(sc)
-    osc = oracle.scene(sc)
-    depth = ctx.scene_info().bvh_max_depth
-    assert depth >= 24, depth         # 2*depth+2 stack entries + 16 deferred: beyond what the kernel keeps in LDS
     rng = np.random.default_rng(2)
     rays = np.zeros(6000, dtype=api.RAY_DTYPE)
     r = 1.028 ** rng.uniform(0, n, 6000)
@@ -242,6 +237,17 @@ def test_deep_hierarchy_with_every_stack_configuration(ctx, oracle):
     d = np.stack([rng.normal(0, 0.2, 6000), rng.normal(0, 0.2, 6000), np.ones(6000)], axis=1)
     rays["dir"] = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
     rays["tmin"], rays["tmax"] = 0.0, 1e30
+    return sc, rays
+
+
+def test_deep_hierarchy_with_every_stack_configuration(ctx, oracle):
+    """A hierarchy far deeper than the LDS part of the traversal stack: the LDS clamp, the spill region and the
+    deferred queue must all give the brute-force answer."""
+    sc, rays = deep_hierarchy_scene()
+    ctx.scene_create(sc)
+    osc = oracle.scene(sc)
+    depth = ctx.scene_info().bvh_max_depth
+    assert depth >= 24, depth         # 2*depth+2 stack entries + 16 deferred: beyond what the kernel keeps in LDS
     ref = osc.trace_rays(rays, brute=True)
     assert (ref["prim"] != api.PT_MISS).mean() > 0.5
     try:
@@ -884,6 +890,38 @@ def test_api_call_sequences_with_reallocation(oracle):
         hits = cx.primary_hits(cornell_consts(200, 100), 200, 100, 1)     # larger than any wavefront state so far
         assert np.array_equal(hits["prim"], ocornell.primary_hits(cornell_consts(200, 100), 200, 100, 1)["prim"])
         check(ocornell, cornell_consts(64, 64), 64, 64, 0, 2)
+    finally:
+        cx.close()
+
+
+def test_ao_buffers_survive_a_growing_trace_staging_buffer(oracle):
+    """Regression (round-1 review): pt_trace_rays growing its staging buffers used to free the AO ray buffers without
+    resetting their capacity. Order: render_ao -> trace_rays with more rays than ever before -> render_ao again."""
+    from pathtracer_amd.context import Context
+    cx = Context(0)
+    try:
+        atm = oracle.earth_atmosphere()
+        cx.sky_set(atm)
+        olut = oracle.transmittance_lut(atm)
+        sc = scenes.cornell_box()
+        osc = oracle.scene(sc)
+        cx.scene_create(sc)
+        w, h, spp = 80, 60, 2
+        c = cornell_consts(w, h, sky=True)
+        c.myAoDistance = 40.0
+        ref, _ = osc.render_ao(c, w, h, 0, spp, lut=olut)
+        for rnd in range(2):
+            cx.accum_reset(w, h)
+            cx.render_ao(c, w, h, 0, spp)
+            hit_all = oracle_all_samples_hit(osc, c, w, h, 0, spp)
+            img = cx.accum_read_sum()[0]
+            assert np.array_equal(img[hit_all], ref[hit_all]), rnd
+            assert rel_mse(img, ref) < 1e-6, rnd
+            rays = random_rays(3 + rnd, 400000 * (rnd + 1), (-10, 95, -10), (10, 110, 10))   # grows tmp_rays / tmp_hits
+            got = cx.trace_rays(rays)
+            assert np.array_equal(got["prim"], osc.trace_rays(rays)["prim"])
+            occ = cx.occluded(rays[:1000])
+            assert np.array_equal(occ.astype(bool), got["prim"][:1000] != api.PT_MISS)
     finally:
         cx.close()
 
