@@ -295,6 +295,14 @@ int pt_primary_hits(pt_ctx* ctx, const PtRtConsts* consts, uint32_t width, uint3
 int pt_trace_rays(pt_ctx* ctx, const PtRay* rays, uint64_t num_rays, PtHit* hits);
 /* Same on DEVICE arrays already resident (used by the bench): no copies, asynchronous. */
 int pt_trace_rays_device(pt_ctx* ctx, const PtRay* device_rays, uint64_t num_rays, PtHit* device_hits);
+/* pt_trace_rays_device for callers that cannot allocate device memory (code under HIP graph capture, tight serving
+ * loops, harnesses that forbid hipMalloc). NO counterpart in the reference. It calls no hipMalloc / hipFree / allocating
+ * routine: the kernel's counters and the spill region of its traversal stacks live in a static 64 MiB device array
+ * that every GPU the library runs on holds until the process ends. Limits: num_rays < 2^31; the scene's BVH must be
+ * shallow enough that the spill of one block per CU fits the array (PT_ERR_UNSUPPORTED otherwise; every BASELINE scene
+ * fits) — deeper scenes only shrink the persistent grid. Same results as pt_trace_rays_device, bit for bit. All calls on
+ * one GPU share that GPU's array (whatever the ctx or stream): calls that overlap on one GPU race. */
+int pt_trace_rays_device_noalloc(pt_ctx* ctx, const PtRay* device_rays, uint64_t num_rays, PtHit* device_hits);
 /* Evaluate one shading/sky device function on n rows of host inputs (see PT_FN_* for row layouts). */
 int pt_debug_eval(pt_ctx* ctx, int fn, const PtRtConsts* consts, const float* in, uint64_t n, float* out);
 /* Copy out the ray queue that the LAST wavefront batch built for `bounce` (valid until the next render call; the

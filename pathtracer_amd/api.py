@@ -159,6 +159,7 @@ SYMBOLS = {
     "pt_primary_hits": (C.c_int, [_P, C.POINTER(PtRtConsts), C.c_uint32, C.c_uint32, C.c_uint32, _P]),
     "pt_trace_rays": (C.c_int, [_P, _P, C.c_uint64, _P]),
     "pt_trace_rays_device": (C.c_int, [_P, _P, C.c_uint64, _P]),
+    "pt_trace_rays_device_noalloc": (C.c_int, [_P, _P, C.c_uint64, _P]),
     "pt_occluded": (C.c_int, [_P, _P, C.c_uint64, _P]),
     "pt_debug_eval": (C.c_int, [_P, C.c_int, C.POINTER(PtRtConsts), _P, C.c_uint64, _P]),
     "pt_debug_read_queue": (C.c_int, [_P, C.c_uint32, _P, C.c_uint64, C.POINTER(C.c_uint64)]),

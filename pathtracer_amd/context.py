@@ -184,6 +184,9 @@ class Context:
     def trace_rays_device(self, rays_ptr, n, hits_ptr):
         self._ck(self.lib.pt_trace_rays_device(self.h, C.c_void_p(rays_ptr), int(n), C.c_void_p(hits_ptr)))
 
+    def trace_rays_device_noalloc(self, rays_ptr, n, hits_ptr):
+        self._ck(self.lib.pt_trace_rays_device_noalloc(self.h, C.c_void_p(rays_ptr), int(n), C.c_void_p(hits_ptr)))
+
     def debug_eval(self, fn, rows, consts=None):
         rows = np.ascontiguousarray(rows, dtype=np.float32).reshape(-1, api.FN_IN_WIDTH[fn])
         out = np.empty((len(rows), api.FN_OUT_WIDTH[fn]), dtype=np.float32)

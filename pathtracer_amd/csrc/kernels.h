@@ -56,6 +56,12 @@ struct WavefrontBuffers {
 
 #define PT_EXTEND_MAX_LDS_ENTRIES 64u   // stack + deferred-queue entries per lane kept in LDS (128 KB per block at most)
 
+// Static device scratch of pt_trace_rays_device_noalloc (kernels.hip): [0,256) ray-count line, [256,512) work-cursor
+// line, [512, PT_SCRATCH_BYTES) spill region of the per-lane traversal stacks.
+#define PT_SCRATCH_BYTES (64u << 20)
+#define PT_SCRATCH_HEADER 512u
+hipError_t scratch_address(void** out);   // address of the CURRENT device's copy of the array
+
 struct LaunchCfg {
   int num_cus = 256;
   int extend_blocks = 1024;   // persistent grid of the extend kernel

@@ -805,6 +805,22 @@ void launch_add(float4* dst, const float4* src, uint64_t n, hipStream_t s) {
   hipLaunchKernelGGL(k_add, dim3(grid_for(n, 0)), dim3(256), 0, s, dst, src, n);
 }
 
+// ------------------------------------------------------------------------------------------------ static scratch
+// Device memory of the entry point that allocates nothing (pt_trace_rays_device_noalloc): the two counter lines of the
+// extend kernel and the spill region of its per-lane stacks live in this file-scope array instead of hipMalloc'ed
+// buffers. Every GPU the library runs on holds its own copy at its own address until the process ends. In host code
+// the array's NAME is only a handle for hipGetSymbolAddress: the address that kernels, memsets and copies use is the
+// one this function returns (looked up once per device by pt_create, with that device current).
+static __device__ __align__(256) unsigned char scratch[PT_SCRATCH_BYTES];
+
+hipError_t scratch_address(void** out) {
+  *out = nullptr;
+  void* p = nullptr;
+  const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+  if (e == hipSuccess) *out = p;
+  return e;
+}
+
 void launch_set_count(uint32_t* counter, uint32_t value, hipStream_t s) {
   hipLaunchKernelGGL(k_set_count, dim3(1), dim3(1), 0, s, counter, value);
 }

@@ -69,6 +69,7 @@ struct pt_ctx {
   float4* tmp_rays = nullptr;   // staging for pt_trace_rays (AoS PtRay)
   float4* tmp_hits = nullptr;
   uint64_t tmp_capacity = 0;
+  unsigned char* scratch = nullptr;   // this device's copy of the library's static scratch array (pt_trace_rays_device_noalloc)
 
   // options
   bool count_traversal = false;
@@ -300,6 +301,16 @@ int pt_create(int device, pt_ctx** out_ctx) {
     return PT_ERR_HIP;
   }
   ctx->stream = ctx->own_stream;
+  {
+    void* sp = nullptr;
+    if ((e = scratch_address(&sp)) != hipSuccess) {   // once per device: every ctx of a device sees the same address
+      g_create_error = std::string("hipGetSymbolAddress(scratch): ") + hipGetErrorString(e);
+      (void)hipStreamDestroy(ctx->own_stream);
+      delete ctx;
+      return PT_ERR_HIP;
+    }
+    ctx->scratch = (unsigned char*)sp;
+  }
   ctx->cfg.stream_blocks = ctx->cfg.num_cus * 8;
   ctx->cfg.extend_blocks = ctx->cfg.num_cus * 4;
   *out_ctx = ctx;
@@ -803,6 +814,38 @@ int pt_trace_rays_device(pt_ctx* ctx, const PtRay* device_rays, uint64_t num_ray
   launch_set_count(ctx->wb.counters + CTR_AT(CTR_QCOUNT0), (uint32_t)num_rays, ctx->stream);
   const float4* base = (const float4*)device_rays;  // AoS: {origin,tmin},{dir,tmax}
   extend_one(ctx, base, base + 1, 2, (float4*)device_hits, ctx->wb.counters + CTR_AT(CTR_QCOUNT0), ctx->wb.counters + CTR_AT(CTR_WORK0));
+  PT_HIP(hipGetLastError());
+  return PT_OK;
+}
+
+int pt_trace_rays_device_noalloc(pt_ctx* ctx, const PtRay* device_rays, uint64_t num_rays, PtHit* device_hits) {
+  PT_REQUIRE_CTX();
+  if (!ctx->has_scene) return ctx->fail(PT_ERR_NO_SCENE, "pt_trace_rays_device_noalloc before pt_scene_create");
+  if (num_rays == 0) return PT_OK;
+  if (!device_rays || !device_hits) return ctx->fail(PT_ERR_INVALID_ARG, "null ray or hit array");
+  if (num_rays >= (1ull << 31)) return ctx->fail(PT_ERR_INVALID_ARG, "pt_trace_rays_device_noalloc: at most 2^31 - 1 rays per call");
+  // The spill region of the per-lane stacks comes out of the static scratch, so the persistent grid is cut to the
+  // waves it has room for; a BVH so deep that not even one block per CU fits is rejected.
+  LaunchCfg cfg = ctx->cfg;
+  const uint32_t lds_entries = std::min<uint32_t>(std::min(ctx->ds.stack_entries, cfg.lds_stack_entries), PT_EXTEND_MAX_LDS_ENTRIES - cfg.defer_entries);
+  const uint64_t spill_bytes_per_wave = (uint64_t)(ctx->ds.stack_entries - lds_entries) * 64u * sizeof(uint2);
+  if (spill_bytes_per_wave) {
+    const uint64_t blocks_fit = (PT_SCRATCH_BYTES - PT_SCRATCH_HEADER) / spill_bytes_per_wave / 4u;
+    if (blocks_fit < (uint64_t)cfg.num_cus)
+      return ctx->fail(PT_ERR_UNSUPPORTED, "pt_trace_rays_device_noalloc: the scene's BVH (" + std::to_string(ctx->info.bvh_max_depth) +
+                                               " levels) needs " + std::to_string(spill_bytes_per_wave) + " bytes of stack spill per wave; the " +
+                                               std::to_string(PT_SCRATCH_BYTES >> 20) + " MiB static scratch cannot hold one block per CU");
+    cfg.extend_blocks = (int)std::min<uint64_t>((uint64_t)cfg.extend_blocks, blocks_fit);
+  }
+  uint32_t* count = (uint32_t*)ctx->scratch;
+  uint32_t* cursor = (uint32_t*)(ctx->scratch + 256);
+  PT_HIP(hipMemsetAsync(ctx->scratch, 0, PT_SCRATCH_HEADER, ctx->stream));   // the array keeps the last call's contents
+  launch_set_count(count, (uint32_t)num_rays, ctx->stream);
+  DeviceScene ds = ctx->ds;
+  ds.spill = (uint2*)(ctx->scratch + PT_SCRATCH_HEADER);
+  const float4* base = (const float4*)device_rays;
+  launch_extend(ds, base, base + 1, 2, (float4*)device_hits, count, cursor, nullptr, false, false, cfg, ctx->stream);
+  ctx->extend_launches++;
   PT_HIP(hipGetLastError());
   return PT_OK;
 }
