@@ -26,6 +26,9 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 VALU_PEAK_GINSTR = 1228.8      # wave64 VALU instructions/s: 256 CUs x 4 SIMD32 x 2.4 GHz / 2 cycles (MI355X_MICROARCH.md)
 NODE_BYTES, TRI_BYTES, RAY_IO_BYTES = 80, 48, 48   # B_ray = 80*N_node + 48*N_tri + 48
+NODE_FLOP, TRI_FLOP = 176.0, 45.0                  # F_ray = 8*22*N_node + 45*N_tri
+FP32_PEAK_TFLOPS = 157.3                           # MI355X_MICROARCH.md: peak fp32 vector
+PMC_ROUND = "r02"                                  # profiles/<round>/pmc_traffic.json: counters of THIS build
 DEF_DEFER, DEF_POSTPONE = 4, 50                   # the library defaults (csrc/kernels.h LaunchCfg)
 
 
@@ -68,6 +71,18 @@ def main():
     ap.add_argument("--all-ranks-on-gpu0", action="store_true", help="rehearsal: every rank uses cuda:0")
     args = ap.parse_args()
 
+    # --gpus N without a launcher: start the N ranks ourselves (one process per GPU, torch.distributed.run), BEFORE
+    # anything touches torch or the GPU in this process, and hand back the children's exit code.
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
+
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -79,6 +94,10 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.all_ranks_on_gpu0:
         local_rank = 0
+    if world != max(1, args.gpus):
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
+              f"(python bench.py --gpus N does it by itself)", file=sys.stderr)
+        sys.exit(2)
     if world > 1:
         torch.cuda.set_device(local_rank)
         if args.backend == "nccl":
@@ -191,42 +210,62 @@ def main():
         se = ctx.stats()
         ctx.set_option(api.PT_OPT_TIME_KERNELS, 0)
         ext_s = se.extend_ms * 1e-3
-        achieved = bytes_per_ray * se.rays / max(ext_s, 1e-12) / 1e9
-        # (3) measured memory-side traffic of the same kernel: PMC counters cannot be read from inside this process, so the
-        #     figure comes from the committed rocprofv3 --pmc passes of this command (tools/prof_pmc.sh ->
-        #     tools/pmc_traffic.py -> profiles/r01/pmc_traffic.json), matched on workload, size and batch; null otherwise.
-        traffic, traffic_note, valu = None, "no PMC profile committed for this workload/size", None
+        # (3) counters that cannot be read from inside this process (rocprofv3 --pmc passes of this same command,
+        #     tools/prof_pmc.sh -> tools/pmc_traffic.py -> profiles/r02/pmc_traffic.json, matched on workload, size,
+        #     batch and depth): VALU wave-instructions and fabric-side bytes per extend launch of THIS build.
+        pmc = None
         try:
-            with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01", "pmc_traffic.json")) as f:
+            with open(os.path.join(ROOT, "profiles", PMC_ROUND, "pmc_traffic.json")) as f:
                 for e in json.load(f):
-                    if (e["workload"], e["width"], e["height"], e["spp_per_step"], e["depth"]) == (args.workload, W, H, SPP, depth):
-                        traffic = e["extend_bytes_per_launch"]
-                        traffic_note = e["note"]
-                        if e.get("extend_valu_wave_instr_per_launch"):
-                            valu = {"wave_instr_per_launch": e["extend_valu_wave_instr_per_launch"],
-                                    "lanes_active_per_instr": e.get("extend_lanes_active_per_valu_instr")}
+                    if (e["workload"], e["width"], e["height"], e["spp_per_step"], e["depth"]) == (args.workload, W, H, SPP, depth) \
+                            and (e.get("material_ext", 0), e.get("russian_roulette", 0)) == (args.material_ext, args.russian_roulette):
+                        pmc = e
         except (OSError, ValueError, KeyError):
             pass
+        launches = max(1, se.extend_launches)
+        launch_s = se.extend_ms / launches * 1e-3
+        alg_bytes = bytes_per_ray * se.rays / launches
+        alg_flop = (NODE_FLOP * nodes_per_ray + TRI_FLOP * tris_per_ray) * se.rays / launches
+        hbm = {"algorithmic_bytes_per_launch": round(alg_bytes, 1), "achieved_gbs": round(alg_bytes / launch_s / 1e9, 2),
+               "peak_gbs": HBM_PEAK_GBS, "ratio_to_hbm_peak": round(alg_bytes / launch_s / 1e9 / HBM_PEAK_GBS, 4),
+               "note": "SURVEY 8(d) B_ray x rays; the BVH is served from L1/L2/Infinity Cache when it fits (C2 14.7 MB, C4 176 MB), "
+                       "so this ratio can exceed 1 and HBM is then not the binding roof"}
+        flops = {"algorithmic_flop_per_launch": round(alg_flop, 1), "achieved_tflops": round(alg_flop / launch_s / 1e12, 3),
+                 "peak_tflops": FP32_PEAK_TFLOPS, "frac": round(alg_flop / launch_s / 1e12 / FP32_PEAK_TFLOPS, 4),
+                 "note": "SURVEY 8(d): 176 flop per node visited + 45 per triangle tested, canonical schedule"}
+        traffic = pmc["extend_bytes_per_launch"] if pmc else None
+        fabric = ({"bytes_per_launch": traffic, "achieved_gbs": round(traffic / launch_s / 1e9, 2),
+                   "frac_of_hbm_peak": round(traffic / launch_s / 1e9 / HBM_PEAK_GBS, 4), "note": pmc["note"]} if traffic else None)
+        valu = None
+        if pmc and pmc.get("extend_valu_wave_instr_per_launch"):
+            # the profiled command runs the same batch, so its per-launch instruction count belongs to these launches
+            g = pmc["extend_valu_wave_instr_per_launch"] / launch_s / 1e9
+            valu = {"wave_instr_per_launch": pmc["extend_valu_wave_instr_per_launch"],
+                    "lanes_active_per_instr": pmc.get("extend_lanes_active_per_valu_instr"),
+                    "achieved_ginstr_per_s": round(g, 1), "peak_ginstr_per_s": VALU_PEAK_GINSTR, "frac": round(g / VALU_PEAK_GINSTR, 4)}
+        # The binding roof is the larger measured fraction: VALU issue (PMC instruction count / live launch time) or
+        # fabric-side traffic against the HBM peak. Without a PMC profile of this build + workload the line falls back to
+        # the algorithmic fp32 rate against the vector peak (never above 1).
+        if valu and (not fabric or valu["frac"] >= fabric["frac_of_hbm_peak"]):
+            top = {"bound": "valu", "achieved": valu["achieved_ginstr_per_s"], "peak": VALU_PEAK_GINSTR, "unit": "Ginstr/s", "frac": valu["frac"],
+                   "basis": "SQ_INSTS_VALU per launch (profiles/%s/pmc_traffic.json) / live HIP-event launch time; peak = 256 CUs x 4 SIMD x 2.4 GHz / 2 cycles" % PMC_ROUND}
+        elif fabric:
+            top = {"bound": "hbm", "achieved": fabric["achieved_gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": fabric["frac_of_hbm_peak"],
+                   "basis": "measured fabric-side bytes per launch (profiles/%s/pmc_traffic.json) / live HIP-event launch time" % PMC_ROUND}
+        else:
+            top = {"bound": "valu", "achieved": flops["achieved_tflops"], "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": flops["frac"],
+                   "basis": "algorithmic fp32 flops (no PMC profile committed for this workload/size/build)"}
         roofline = {
-            "bound": "hbm", "kernel": "k_extend", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_note": traffic_note,
-            # measured fabric-side bandwidth of the kernel (traffic / launch time) as a fraction of the same peak
-            "traffic_frac": (round(traffic / (se.extend_ms / max(1, se.extend_launches) * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
-                             if traffic else None),
-            # secondary bound (north star: "fraction of HBM/VALU roofline"): VALU issue. Instruction count per launch from
-            # the same PMC profile; peak = 256 CUs x 4 SIMDs x 2.4 GHz / 2 cycles per wave64 instruction.
-            "valu": ({**valu, "achieved_ginstr_per_s": round(valu["wave_instr_per_launch"] / (se.extend_ms / max(1, se.extend_launches) * 1e-3) / 1e9, 1),
-                      "peak_ginstr_per_s": VALU_PEAK_GINSTR,
-                      "frac": round(valu["wave_instr_per_launch"] / (se.extend_ms / max(1, se.extend_launches) * 1e-3) / 1e9 / VALU_PEAK_GINSTR, 4)}
-                     if valu else None),
+            **top, "kernel": "k_extend", "traffic": traffic,
+            "hbm_algorithmic": hbm, "fabric": fabric, "valu_issue": valu, "flops_algorithmic": flops,
             "nodes_per_ray": round(nodes_per_ray, 3), "tris_per_ray": round(tris_per_ray, 3),
             "shipped_schedule": {"nodes_per_ray": round(ship.nodes_visited / max(1, ship.rays), 3),
                                  "tris_per_ray": round(ship.tris_tested / max(1, ship.rays), 3),
                                  "node_phase_lane_util": round(ship.nodes_visited / max(1, 64 * ship.node_wave_steps), 3),
                                  "tri_phase_lane_util": round(ship.tris_tested / max(1, 64 * ship.tri_wave_steps), 3)},
             "bytes_per_ray": round(bytes_per_ray, 1),
-            "launches": int(se.extend_launches), "avg_launch_ms": round(se.extend_ms / max(1, se.extend_launches), 4),
-            "bytes_per_launch": round(bytes_per_ray * se.rays / max(1, se.extend_launches), 1),
+            "launches": int(se.extend_launches), "avg_launch_ms": round(se.extend_ms / launches, 4),
+            "bytes_per_launch": round(alg_bytes, 1),
             "extend_share_of_render": round(se.extend_ms / max(se.render_ms, 1e-9), 4),
             "extend_mrays_per_s": round(se.rays / max(ext_s, 1e-12) / 1e6, 2),
             "extend_mrays_per_s_by_bounce": [round(se.rays_bounce[b] / max(se.extend_ms_bounce[b], 1e-9) / 1e3, 1)

@@ -308,6 +308,11 @@ int pt_debug_eval(pt_ctx* ctx, int fn, const PtRtConsts* consts, const float* in
 /* Copy out the ray queue that the LAST wavefront batch built for `bounce` (valid until the next render call; the
    queue of bounce b is overwritten by bounce b+2 of the same batch). host_rays may be NULL to query the count. */
 int pt_debug_read_queue(pt_ctx* ctx, uint32_t bounce, PtRay* host_rays, uint64_t capacity, uint64_t* count_out);
+/* Copy the acceleration structure as it lives on the device back to the host: 80-byte nodes and 48-byte triangle
+   records (layout: pathtracer_amd/csrc/bvh8.h), plus the scene magnitude the box test's overflow guard uses. With both
+   arrays NULL only the counts are returned. Lets tests walk the very hierarchy the kernel walks (tests/walker/). */
+int pt_debug_read_bvh(pt_ctx* ctx, void* nodes, uint64_t node_capacity, void* tris, uint64_t tri_capacity,
+                      uint64_t* num_nodes, uint64_t* num_tris, float* scene_mag);
 int pt_stats_get(pt_ctx* ctx, PtStats* out);   /* synchronises the stream first */
 int pt_stats_reset(pt_ctx* ctx);
 

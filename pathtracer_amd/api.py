@@ -163,6 +163,7 @@ SYMBOLS = {
     "pt_occluded": (C.c_int, [_P, _P, C.c_uint64, _P]),
     "pt_debug_eval": (C.c_int, [_P, C.c_int, C.POINTER(PtRtConsts), _P, C.c_uint64, _P]),
     "pt_debug_read_queue": (C.c_int, [_P, C.c_uint32, _P, C.c_uint64, C.POINTER(C.c_uint64)]),
+    "pt_debug_read_bvh": (C.c_int, [_P, _P, C.c_uint64, _P, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_float)]),
     "pt_stats_get": (C.c_int, [_P, C.POINTER(PtStats)]),
     "pt_stats_reset": (C.c_int, [_P]),
 }

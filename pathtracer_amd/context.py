@@ -201,6 +201,15 @@ class Context:
         self._ck(self.lib.pt_debug_read_queue(self.h, bounce, api.ptr(out), n.value, C.byref(n)))
         return out
 
+    def debug_read_bvh(self):
+        """(nodes uint8[n,80], tris uint8[m,48], scene_mag): the BVH8 as it lives on the device (csrc/bvh8.h)."""
+        nn, nt, mag = C.c_uint64(), C.c_uint64(), C.c_float()
+        self._ck(self.lib.pt_debug_read_bvh(self.h, None, 0, None, 0, C.byref(nn), C.byref(nt), C.byref(mag)))
+        nodes = np.empty((max(1, nn.value), 80), dtype=np.uint8)
+        tris = np.empty((max(1, nt.value), 48), dtype=np.uint8)
+        self._ck(self.lib.pt_debug_read_bvh(self.h, api.ptr(nodes), nn.value, api.ptr(tris), nt.value, None, None, None))
+        return nodes[:nn.value], tris[:nt.value], mag.value
+
     # ---- misc ----
     def set_option(self, opt, value):
         self._ck(self.lib.pt_set_option(self.h, opt, int(value)))

@@ -937,6 +937,27 @@ int pt_debug_read_queue(pt_ctx* ctx, uint32_t bounce, PtRay* host_rays, uint64_t
   return PT_OK;
 }
 
+int pt_debug_read_bvh(pt_ctx* ctx, void* nodes, uint64_t node_capacity, void* tris, uint64_t tri_capacity, uint64_t* num_nodes,
+                      uint64_t* num_tris, float* scene_mag) {
+  PT_REQUIRE_CTX();
+  if (!ctx->has_scene) return ctx->fail(PT_ERR_NO_SCENE, "pt_debug_read_bvh before pt_scene_create");
+#if PT_NODE_STRIDE_U4 != 5
+  return ctx->fail(PT_ERR_UNSUPPORTED, "pt_debug_read_bvh needs packed 80-byte nodes");
+#else
+  const uint64_t nn = ctx->info.num_bvh_nodes;
+  const uint64_t nt = (ctx->info.bvh_bytes - nn * sizeof(PtBvh8Node)) / sizeof(PtTriRecord);
+  if (num_nodes) *num_nodes = nn;
+  if (num_tris) *num_tris = nt;
+  if (scene_mag) *scene_mag = ctx->ds.scene_mag;
+  if (!nodes && !tris) return PT_OK;
+  if (!nodes || !tris || node_capacity < nn || tri_capacity < nt) return ctx->fail(PT_ERR_INVALID_ARG, "pt_debug_read_bvh: arrays too small");
+  PT_HIP(hipStreamSynchronize(ctx->stream));
+  if (nn) PT_HIP(hipMemcpy(nodes, ctx->ds.nodes, nn * sizeof(PtBvh8Node), hipMemcpyDeviceToHost));
+  if (nt) PT_HIP(hipMemcpy(tris, ctx->ds.tris, nt * sizeof(PtTriRecord), hipMemcpyDeviceToHost));
+  return PT_OK;
+#endif
+}
+
 int pt_stats_get(pt_ctx* ctx, PtStats* out) {
   PT_REQUIRE_CTX();
   if (!out) return ctx->fail(PT_ERR_INVALID_ARG, "output pointer is null");

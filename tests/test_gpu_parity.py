@@ -396,7 +396,8 @@ def test_cornell_image_vs_oracle_and_fixture(ctx, cornell):
     assert rel_mse(img, np.load(os.path.join(G, "cornell_128_16spp.npy"))) < 1e-8
     assert (img[..., 3] == 0).all() and np.isfinite(img).all()
     st = ctx.stats()
-    assert st.samples == w * h * 16 and abs(int(st.rays) - ost["rays"]) <= 8 and abs(int(st.shaded_hits) - ost["shaded_hits"]) <= 8
+    print("cornell rays", st.rays, ost["rays"], "shaded", st.shaded_hits, ost["shaded_hits"])
+    assert st.samples == w * h * 16 and abs(int(st.rays) - ost["rays"]) <= 3 and abs(int(st.shaded_hits) - ost["shaded_hits"]) <= 3   # observed: 1 and 0
     # per-sample agreement: render sample 5 alone and compare with the oracle's per-sample radiance
     ctx.accum_reset(w, h)
     ctx.render(c, w, h, 5, 1)
@@ -481,9 +482,201 @@ def test_street_3m_triangles_hits_and_image_match_oracle(ctx, oracle):
     img = ctx.accum_read()
     st = ctx.stats()
     acc, ost, _ = osc.render(c, w, h, 0, 2, lut=olut)
-    assert abs(st.rays - ost["rays"]) <= 1e-3 * ost["rays"]
-    assert abs(st.sky_misses - ost["sky_misses"]) <= 1e-3 * ost["sky_misses"] + 2
+    print("street rays", st.rays, ost["rays"], "sky", st.sky_misses, ost["sky_misses"])
+    # observed on MI355X: 7 of 116,757 rays (6e-5): the bound is about twice that, not a blanket 1e-3
+    assert abs(st.rays - ost["rays"]) <= 1.5e-4 * ost["rays"]
+    assert abs(st.sky_misses - ost["sky_misses"]) <= 1.5e-4 * ost["sky_misses"] + 2
     assert rel_mse(img, acc / 2.0) < 1e-4, rel_mse(img, acc / 2.0)
+
+
+# ---------------------------------------------------------------------------------------------- BASELINE C4 / C5 as stated
+def test_street_c4_with_ggx_material_extension_matches_oracle(ctx, oracle):
+    """BASELINE config C4 as it is worded ("~3M tris, 8 bounces, textured GGX materials"): street(2) with the material
+    extension (GGX lobes + procedural albedo patterns) on every material, depth 8, against the oracle's restatement."""
+    sc = scenes.with_material_ext(scenes.street(2))
+    ctx.scene_create(sc)
+    osc = oracle.scene(sc)
+    assert ctx.scene_info().num_triangles == 3145728
+    atm = oracle.earth_atmosphere()
+    ctx.sky_set(atm)
+    olut = oracle.transmittance_lut(atm)
+    w, h, spp = 160, 90, 2
+    c = lookat_consts(w, h, scenes.STREET_CAM, depth=8)
+    ctx.accum_reset(w, h)
+    ctx.stats_reset()
+    ctx.render(c, w, h, 0, spp)
+    img = ctx.accum_read()
+    st = ctx.stats()
+    acc, ost, _ = osc.render(c, w, h, 0, spp, lut=olut)
+    print("street+ext rays", st.rays, ost["rays"], "relMSE", rel_mse(img, acc / spp))
+    assert abs(st.rays - ost["rays"]) <= 6e-5 * ost["rays"]      # observed: 3 of 122,167
+    assert rel_mse(img, acc / spp) < 1e-4, rel_mse(img, acc / spp)
+    assert st.rays / st.samples > 2.0                   # the depth-8 paths really bounce
+
+
+def test_courtyard_c5_10m_triangles_depth16_russian_roulette(ctx, oracle):
+    """BASELINE config C5: courtyard(3) at its full 10,485,760 triangles (585 MB of BVH: beyond the 256 MB Infinity
+    Cache), depth 16 (<= 17 rays per sample, PathTracing.hlsl:68), Russian roulette on. 200 k incoherent rays bit-identical
+    to the oracle's own BVH; a small image within the north-star tolerance with ray counts within 5e-5."""
+    sc = scenes.courtyard(3)
+    ctx.scene_create(sc)
+    info = ctx.scene_info()
+    assert info.num_triangles == 10485760 and info.bvh_bytes > 256 * 2 ** 20
+    osc = oracle.scene(sc)
+    rays = random_rays(51, 200000, list(info.bounds_min), list(info.bounds_max), tmin=0.001, tmax=10000.0)
+    got, ref = ctx.trace_rays(rays), osc.trace_rays(rays)
+    assert np.array_equal(got["prim"], ref["prim"])
+    hit = ref["prim"] != api.PT_MISS
+    assert 0.3 < hit.mean() < 1.0
+    for f in ("t", "u", "v"):
+        assert np.array_equal(got[f][hit].view(np.uint32), ref[f][hit].view(np.uint32)), f
+    atm = oracle.earth_atmosphere()
+    ctx.sky_set(atm)
+    olut = oracle.transmittance_lut(atm)
+    w, h, spp = 128, 72, 4
+    c = lookat_consts(w, h, scenes.COURTYARD_CAM, depth=16)
+    try:
+        ctx.set_option(api.PT_OPT_RUSSIAN_ROULETTE, 1)
+        oracle.set_russian_roulette(1)
+        ctx.accum_reset(w, h)
+        ctx.stats_reset()
+        ctx.render(c, w, h, 0, spp)
+        img = ctx.accum_read()
+        st = ctx.stats()
+        acc, ost, _ = osc.render(c, w, h, 0, spp, lut=olut)
+    finally:
+        ctx.set_option(api.PT_OPT_RUSSIAN_ROULETTE, 0)
+        oracle.set_russian_roulette(0)
+    print("courtyard rays", st.rays, ost["rays"], "relMSE", rel_mse(img, acc / spp))
+    assert abs(st.rays - ost["rays"]) <= 5e-5 * ost["rays"]      # observed: identical (114,518)
+    assert abs(st.sky_misses - ost["sky_misses"]) <= 5e-5 * ost["sky_misses"] + 2
+    assert rel_mse(img, acc / spp) < 1e-4, rel_mse(img, acc / spp)
+    assert max(b for b in range(16) if st.rays_bounce[b] > 0) >= 8       # long paths exist
+
+
+# ---------------------------------------------------------------------------------------------- roofline inputs
+def test_count_kernel_matches_host_walker_on_the_same_bvh8(ctx, oracle):
+    """bench.py's roofline is built on nodes / triangles per ray reported by the COUNT instantiation of k_extend. A
+    second implementation (tests/walker/bvh8_walker.cpp: scalar host walker over the very BVH8 the device holds, read
+    back with pt_debug_read_bvh, canonical schedule) must report the same totals and the same hit records."""
+    import ctypes as C
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    so = os.path.join(root, "tests", "walker", "libbvh8_walker.so")
+    assert os.path.exists(so), "build tests/walker first (__graft_entry__.build())"
+    wl = C.CDLL(so)
+    P = C.c_void_p
+    wl.bvh8_walk.restype = C.c_int
+    wl.bvh8_walk.argtypes = [P, C.c_uint64, P, C.c_uint64, C.c_float, P, C.c_uint64, P, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    sc = scenes.atrium(1)
+    ctx.scene_create(sc)
+    info = ctx.scene_info()
+    nodes, tris, mag = ctx.debug_read_bvh()
+    assert len(nodes) == info.num_bvh_nodes and len(tris) == info.num_triangles
+    rays = random_rays(77, 100000, list(info.bounds_min), list(info.bounds_max), tmin=0.001, tmax=10000.0)
+    whits = np.empty(len(rays), dtype=api.HIT_DTYPE)
+    cn, ct = C.c_uint64(), C.c_uint64()
+    assert wl.bvh8_walk(api.ptr(nodes), len(nodes), api.ptr(tris), len(tris), mag, api.ptr(rays), len(rays), api.ptr(whits),
+                        C.byref(cn), C.byref(ct)) == 0
+    try:
+        ctx.set_option(api.PT_OPT_EXTEND_DEFER, 0)
+        ctx.set_option(api.PT_OPT_EXTEND_POSTPONE_PCT, 0)        # canonical schedule: what bench.py's count_pass(0, 0) runs
+        ctx.set_option(api.PT_OPT_COUNT_TRAVERSAL, 1)
+        ctx.stats_reset()
+        got = ctx.trace_rays(rays)
+        st = ctx.stats()
+    finally:
+        ctx.set_option(api.PT_OPT_COUNT_TRAVERSAL, 0)
+        ctx.set_option(api.PT_OPT_EXTEND_DEFER, 4)
+        ctx.set_option(api.PT_OPT_EXTEND_POSTPONE_PCT, 50)
+    assert np.array_equal(got.view(np.uint32), whits.view(np.uint32))
+    assert (st.nodes_visited, st.tris_tested) == (cn.value, ct.value)
+    assert 5 < cn.value / len(rays) < 60 and 1 < ct.value / len(rays) < 40
+    assert np.array_equal(whits["prim"], oracle.scene(sc).trace_rays(rays)["prim"])      # and the oracle's own BVH agrees
+
+
+# ---------------------------------------------------------------------------------------------- f3 / f2 against the oracle
+def test_sky_view_lut_against_the_oracle_march(ctx, oracle):
+    """sky mode 1 "within relMSE 1e-4 of the marched ORACLE" (SampleSky.hlsl:7-47 restated in
+    oracle/sky.h), not merely of the library's own march: 50 k directions through PT_FN_SKY_VIEW_LUT vs
+    orc_eval(PT_FN_SKY), and a mode-1 atrium image vs orc_render."""
+    atm = oracle.earth_atmosphere()
+    ctx.sky_set(atm)
+    olut = oracle.transmittance_lut(atm)
+    for sun_dir in ((0.3, 0.8, 0.52), (-0.7, 0.12, 0.2)):
+        c = lookat_consts(64, 64, scenes.ATRIUM_CAM, sun_dir=sun_dir)
+        rng = np.random.default_rng(12)
+        n = 50000
+        d = rng.normal(size=(n, 3))
+        d /= np.linalg.norm(d, axis=1, keepdims=True)
+        d[:, 1] = np.abs(d[:, 1])
+        rows = np.concatenate([np.tile(np.asarray(c.myCameraPos, dtype=np.float32), (n, 1)), d], axis=1).astype(np.float32)
+        lut = ctx.debug_eval(api.PT_FN_SKY_VIEW_LUT, rows, c).astype(np.float64)
+        want = oracle.eval(api.PT_FN_SKY, rows, consts=c, lut=olut).astype(np.float64)
+        r = ((lut - want) ** 2).mean() / (want ** 2).mean()
+        assert r < 1e-4, (sun_dir, r)
+    sc = scenes.atrium(1)
+    ctx.scene_create(sc)
+    osc = oracle.scene(sc)
+    w, h, spp = 240, 135, 4
+    c = lookat_consts(w, h, scenes.ATRIUM_CAM)
+    try:
+        ctx.set_option(api.PT_OPT_SKY_MODE, 1)
+        ctx.accum_reset(w, h)
+        ctx.render(c, w, h, 0, spp)
+        img = ctx.accum_read()
+    finally:
+        ctx.set_option(api.PT_OPT_SKY_MODE, 0)
+    acc, _, _ = osc.render(c, w, h, 0, spp, lut=olut)
+    assert rel_mse(img, acc / spp) < 1e-4, rel_mse(img, acc / spp)
+
+
+def test_tonemapped_output_matches_oracle_image(ctx, cornell, oracle, tmp_path):
+    """the output stage (tonemap_composit.hlsl:37-44, Reinhard c/(c+1)) applied by the host mirror to a
+    GPU-accumulated target, against c/(c+1) of the oracle's image; then through the PFM and PNG writers."""
+    from pathtracer_amd import PathTracer, image_io
+    sc, osc = cornell
+    pt = PathTracer(0, 192, 128)
+    try:
+        pt.LoadScene(sc, scenes.CORNELL_CAM_POS)
+        pt.mySampleSky = False
+        pt.mySkyFallbackIntensity = 100.0                # reference default (PathTracer.h:123)
+        pt.RenderRT(8)
+        hdr = pt.ReadOutput()
+        ldr = pt.Tonemap(hdr)
+        acc, _, _ = osc.render(pt.BuildRtConsts(), pt.myOutputWidth, pt.myOutputHeight, 0, 8)
+        ref = acc[..., :3] / 8.0
+        want = ref / (ref + 1.0)
+        assert ldr.shape == want.shape and (ldr >= 0).all() and (ldr < 1).all()
+        assert rel_mse(ldr, want) < 1e-8, rel_mse(ldr, want)
+        assert np.array_equal(ldr, image_io.tonemap_reinhard(hdr))
+        image_io.write_pfm(tmp_path / "o.pfm", ldr)
+        assert np.array_equal(image_io.read_pfm(tmp_path / "o.pfm"), ldr)
+        image_io.write_png(tmp_path / "o.png", ldr)
+        assert open(tmp_path / "o.png", "rb").read(8) == b"\x89PNG\r\n\x1a\n"
+    finally:
+        pt.ctx.close()
+
+
+# ---------------------------------------------------------------------------------------------- bench launcher
+def test_bench_gpus_2_starts_two_ranks_by_itself():
+    """`python bench.py --gpus 2` (the driver's form) must run TWO ranks: rehearsed on this one-GPU box with gloo and
+    both ranks on cuda:0. A --gpus value that disagrees with WORLD_SIZE is an error, not a silent 1-GPU run."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    args = ["--backend", "gloo", "--all-ranks-on-gpu0", "--steps", "1", "--warmup", "1", "--width", "320", "--height", "180",
+            "--spp-per-step", "2", "--no-cpu-baseline", "--no-roofline"]
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"] + args, capture_output=True, text=True, timeout=170, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["value"] > 0 and out["scaling"] == "weak"
+    assert out["config"]["parallelism"] == "sample-partition x2"
+    env["WORLD_SIZE"] = "1"
+    bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"] + args, capture_output=True, text=True, timeout=170, env=env)
+    assert bad.returncode == 2 and "WORLD_SIZE" in bad.stderr
 
 
 # ---------------------------------------------------------------------------------------------- schedule options

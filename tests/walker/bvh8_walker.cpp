@@ -1,0 +1,144 @@
+// bvh8_walker.cpp — TEST INFRASTRUCTURE. A scalar host walker over the compressed 8-wide BVH exactly as the library
+// built it (read back with pt_debug_read_bvh), written from the layout documented in pathtracer_amd/csrc/bvh8.h.
+// It runs the CANONICAL schedule (nearest child first by octant order, every triangle group tested as soon as its node
+// is opened, no postponing / deferral) and counts nodes opened and triangles tested per ray, so that the figures
+// bench.py's roofline is built on (N_node, N_tri of SURVEY §8d) are cross-checked by a second implementation on the
+// SAME hierarchy: tests assert that the kernel's COUNT instantiation reports the same totals and the same hits.
+// Build: g++ -O2 -ffp-contract=off -shared -fPIC (tests/walker/Makefile). The arithmetic that decides a box hit is the
+// kernel's (one fused multiply-add per plane, 1.000001 widening), the triangle test is the watertight test shared
+// with the oracle.
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+#include "../../pathtracer_amd/csrc/bvh8.h"
+
+namespace {
+
+struct Ray { float o[3], tmin, d[3], tmax; };
+struct Hit { float t, u, v; uint32_t prim; };
+
+inline float sel3(const float* x, int k) { return x[k]; }
+
+struct Tri {
+  float o[3]; int kx, ky, kz; float Sx, Sy, Sz;
+  void init(const Ray& r) {
+    for (int a = 0; a < 3; ++a) o[a] = r.o[a];
+    const float ax = std::fabs(r.d[0]), ay = std::fabs(r.d[1]), az = std::fabs(r.d[2]);
+    kz = 0; float m = ax;
+    if (ay > m) { kz = 1; m = ay; }
+    if (az > m) { kz = 2; }
+    kx = kz + 1; if (kx == 3) kx = 0;
+    ky = kx + 1; if (ky == 3) ky = 0;
+    const float dz = r.d[kz];
+    if (dz < 0.0f) { int t = kx; kx = ky; ky = t; }
+    Sx = r.d[kx] / dz; Sy = r.d[ky] / dz; Sz = 1.0f / dz;
+  }
+  void test(const PtTriRecord& T, float tmin, Hit& best) const {
+    const float A[3] = {T.v0[0] - o[0], T.v0[1] - o[1], T.v0[2] - o[2]};
+    const float B[3] = {T.v1[0] - o[0], T.v1[1] - o[1], T.v1[2] - o[2]};
+    const float C[3] = {T.v2[0] - o[0], T.v2[1] - o[1], T.v2[2] - o[2]};
+    const float Akz = A[kz], Bkz = B[kz], Ckz = C[kz];
+    const float Ax = A[kx] - Sx * Akz, Ay = A[ky] - Sy * Akz;
+    const float Bx = B[kx] - Sx * Bkz, By = B[ky] - Sy * Bkz;
+    const float Cx = C[kx] - Sx * Ckz, Cy = C[ky] - Sy * Ckz;
+    float U = Cx * By - Cy * Bx, V = Ax * Cy - Ay * Cx, W = Bx * Ay - By * Ax;
+    if (U == 0.0f || V == 0.0f || W == 0.0f) {
+      U = (float)((double)Cx * (double)By - (double)Cy * (double)Bx);
+      V = (float)((double)Ax * (double)Cy - (double)Ay * (double)Cx);
+      W = (float)((double)Bx * (double)Ay - (double)By * (double)Ax);
+    }
+    if ((U < 0.0f || V < 0.0f || W < 0.0f) && (U > 0.0f || V > 0.0f || W > 0.0f)) return;
+    const float det = U + V + W;
+    if (det == 0.0f) return;
+    const float Az = Sz * Akz, Bz = Sz * Bkz, Cz = Sz * Ckz;
+    const float Tt = U * Az + V * Bz + W * Cz;
+    const float rcp = 1.0f / det;
+    const float t = Tt * rcp;
+    if (!(t > tmin)) return;
+    if (t < best.t || (t == best.t && best.prim != 0xFFFFFFFFu && T.prim < best.prim)) {
+      best.t = t; best.u = V * rcp; best.v = W * rcp; best.prim = T.prim;
+    }
+  }
+};
+
+inline float safe_dir(float d) { return std::fabs(d) < 1e-25f ? std::copysign(1e-25f, d) : d; }
+inline float pow2_from_biased(uint8_t e) { uint32_t b = (uint32_t)e << 23; float f; std::memcpy(&f, &b, 4); return f; }
+
+}  // namespace
+
+extern "C" int bvh8_walk(const PtBvh8Node* nodes, uint64_t num_nodes, const PtTriRecord* tris, uint64_t num_tris, float scene_mag,
+                         const Ray* rays, uint64_t n, Hit* hits, uint64_t* nodes_opened, uint64_t* tris_tested) {
+  uint64_t cn = 0, ct = 0;
+  std::vector<std::pair<uint32_t, uint32_t>> stack;
+  for (uint64_t i = 0; i < n; ++i) {
+    const Ray& r = rays[i];
+    Hit best{r.tmax, 0.0f, 0.0f, 0xFFFFFFFFu};
+    const float chk = (r.o[0] + r.o[1] + r.o[2]) + (r.d[0] + r.d[1] + r.d[2]);
+    if (!std::isfinite(chk)) { hits[i] = Hit{-1.0f, 0.0f, 0.0f, 0xFFFFFFFFu}; continue; }   // non-finite rays miss at once
+    Tri tt; tt.init(r);
+    const float sd[3] = {safe_dir(r.d[0]), safe_dir(r.d[1]), safe_dir(r.d[2])};
+    const float id[3] = {1.0f / sd[0], 1.0f / sd[1], 1.0f / sd[2]};
+    const uint32_t oct = (sd[0] < 0.0f ? 1u : 0u) | (sd[1] < 0.0f ? 2u : 0u) | (sd[2] < 0.0f ? 4u : 0u);
+    const float reach = std::fmax(scene_mag, std::fmax(std::fabs(r.o[0]), std::fmax(std::fabs(r.o[1]), std::fabs(r.o[2]))));
+    const bool risky = !(reach * std::fmax(std::fabs(id[0]), std::fmax(std::fabs(id[1]), std::fabs(id[2]))) < 1e36f);
+    stack.clear();
+    uint32_t gbase = 0u, gbits = 0x80000000u;   // root: one pending internal child at priority 7 of a group with base 0
+    for (;;) {
+      if (gbits > 0x00FFFFFFu) {
+        int b = 31; while (!((gbits >> b) & 1u)) --b;
+        const uint32_t before = gbits;
+        gbits &= ~(1u << b);
+        if (gbits > 0x00FFFFFFu) stack.push_back({gbase, gbits});
+        const uint32_t slot = ((uint32_t)b - 24u) ^ oct;
+        uint32_t rel = 0;
+        for (uint32_t s = 0; s < slot; ++s) rel += (before >> s) & 1u;    // internal children below this slot (imask = low byte)
+        const uint64_t ni = (uint64_t)gbase + rel;
+        if (ni >= num_nodes) return -1;
+        const PtBvh8Node& nd = nodes[ni];
+        ++cn;
+        uint32_t hitmask = 0u;
+        for (int s = 0; s < 8; ++s) {
+          const uint8_t meta = nd.meta[s];
+          float tn = r.tmin, tf = best.t;
+          float tnear[3], tfar[3];
+          for (int a = 0; a < 3; ++a) {
+            const bool neg = (oct >> a) & 1u;
+            const float qn = (float)(neg ? nd.qhi[a][s] : nd.qlo[a][s]), qf = (float)(neg ? nd.qlo[a][s] : nd.qhi[a][s]);
+            const float sc = pow2_from_biased(nd.e[a]), p = nd.p[a] - r.o[a];
+            if (risky) { tnear[a] = std::fmaf(qn, sc, p) * id[a]; tfar[a] = std::fmaf(qf, sc, p) * id[a]; }
+            else { tnear[a] = std::fmaf(qn, sc * id[a], p * id[a]); tfar[a] = std::fmaf(qf, sc * id[a], p * id[a]); }
+          }
+          tn = std::fmax(std::fmax(tnear[0], tnear[1]), std::fmax(tnear[2], r.tmin));
+          tf = std::fmin(std::fmin(tfar[0], tfar[1]), std::fmin(tfar[2], best.t));
+          if (!(tn <= tf * 1.000001f)) continue;
+          const bool inner = (meta & 0x18u) == 0x18u;          // low five bits 0b11sss: only internal children reach 24+
+          const uint32_t bits = meta >> 5;                       // internal: 1; leaf: triangle count in unary
+          const uint32_t pos = inner ? 24u + (((uint32_t)meta & 7u) ^ oct) : ((uint32_t)meta & 0x1fu);
+          hitmask |= bits << pos;
+        }
+        gbase = nd.child_base;
+        gbits = (hitmask & 0xFF000000u) | nd.imask;
+        uint32_t tb = hitmask & 0x00FFFFFFu;
+        while (tb) {                                            // the node's triangle group, lowest index first
+          int k = 0; while (!((tb >> k) & 1u)) ++k;
+          tb &= tb - 1u;
+          const uint64_t ti = (uint64_t)nd.tri_base + (uint32_t)k;
+          if (ti >= num_tris) return -2;
+          ++ct;
+          tt.test(tris[ti], r.tmin, best);
+        }
+      } else if (!stack.empty()) {
+        gbase = stack.back().first; gbits = stack.back().second;
+        stack.pop_back();
+      } else {
+        break;
+      }
+    }
+    if (best.prim == 0xFFFFFFFFu) best.t = -1.0f;
+    hits[i] = best;
+  }
+  *nodes_opened = cn; *tris_tested = ct;
+  return 0;
+}

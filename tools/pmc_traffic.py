@@ -1,4 +1,4 @@
-"""Turns the FETCH_SIZE / WRITE_SIZE passes of tools/prof_pmc.sh into one entry of profiles/r01/pmc_traffic.json.
+"""Turns the FETCH_SIZE / WRITE_SIZE passes of tools/prof_pmc.sh into one entry of profiles/r02/pmc_traffic.json.
 usage: python tools/pmc_traffic.py <tag> <workload> <width> <height> <spp_per_step> <depth>
 Units and corrections follow MI355X_MICROARCH.md (HBM section): FETCH_SIZE/WRITE_SIZE are KB of L2<->fabric requests
 (Infinity-Cache hits included); on gfx950 FETCH_SIZE tallies a 128-byte request as 64 bytes for 16-byte-per-lane reads,
@@ -32,7 +32,7 @@ out["extend_lanes_active_per_valu_instr"] = e["lanes_active_per_valu_instr"] if 
 out["note"] = ("rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE (separate passes), mean over the k_extend launches of bench.py --steps 2; "
                "bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024, the gfx950 doubling of FETCH_SIZE applied although the BVH gathers are "
                "not the calibrated streaming pattern; fabric-side, Infinity-Cache hits included")
-path = "profiles/r01/pmc_traffic.json"
+path = "profiles/r02/pmc_traffic.json"
 cur = json.load(open(path)) if os.path.exists(path) else []
 cur = [c for c in cur if (c["workload"], c["width"], c["height"], c["spp_per_step"], c["depth"]) != (workload, w, h, spp, depth)] + [out]
 json.dump(cur, open(path, "w"), indent=1)
