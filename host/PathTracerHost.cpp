@@ -1,6 +1,10 @@
 // PathTracerHost.cpp — see PathTracerHost.h. Reference: PathTracer/PathTracer.cpp, PathTracer/Sky.cpp.
 #include "PathTracerHost.h"
 
+#include <cerrno>
+#include <climits>
+#include <cstdlib>
+
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -54,8 +58,11 @@ bool ImportObj(const std::string& aPath, SceneData& out, std::string* err) {
   std::vector<Group> groups;
   bool open = false;
   std::string curMat, line;
+  size_t lineNo = 0;
+  auto bad = [&](const std::string& what) { if (err) *err = aPath + ":" + std::to_string(lineNo) + ": " + what; return false; };
   const std::string dir = aPath.find_last_of("/\\") == std::string::npos ? "" : aPath.substr(0, aPath.find_last_of("/\\") + 1);
   while (std::getline(f, line)) {
+    ++lineNo;
     std::istringstream ss(line);
     std::string t;
     ss >> t;
@@ -74,12 +81,26 @@ bool ImportObj(const std::string& aPath, SceneData& out, std::string* err) {
         int part = 0;
         std::string num;
         for (size_t i = 0; i <= c.size(); ++i) {
-          if (i == c.size() || c[i] == '/') { if (!num.empty() && part < 3) k[part] = std::stoi(num); num.clear(); ++part; }
-          else num.push_back(c[i]);
+          if (i == c.size() || c[i] == '/') {
+            if (!num.empty() && part < 3) {   // strtol with full checks: a malformed token is an error, not an exception
+              char* end = nullptr;
+              errno = 0;
+              const long v = std::strtol(num.c_str(), &end, 10);
+              if (errno != 0 || end == num.c_str() || *end != '\0' || v > INT32_MAX || v < -INT32_MAX) return bad("malformed face index '" + c + "'");
+              k[part] = (int)v;
+            }
+            num.clear();
+            ++part;
+          } else num.push_back(c[i]);
         }
+        if (k[0] == 0) return bad("face corner '" + c + "' has no position index (OBJ indices start at 1)");
         k[0] = k[0] > 0 ? k[0] - 1 : (int)pos.size() + k[0];
         k[1] = k[1] > 0 ? k[1] - 1 : (k[1] < 0 ? (int)tex.size() + k[1] : -1);
         k[2] = k[2] > 0 ? k[2] - 1 : (k[2] < 0 ? (int)nrm.size() + k[2] : -1);
+        // every resolved index must name an element read so far (relative indices count back from the current end)
+        if (k[0] < 0 || k[0] >= (int)pos.size()) return bad("position index out of range in '" + c + "'");
+        if (k[1] < -1 || k[1] >= (int)tex.size()) return bad("texture-coordinate index out of range in '" + c + "'");
+        if (k[2] < -1 || k[2] >= (int)nrm.size()) return bad("normal index out of range in '" + c + "'");
         corners.push_back(k);
       }
       for (size_t i = 1; i + 1 < corners.size(); ++i) groups.back().faces.push_back({{corners[0], corners[i], corners[i + 1]}});

@@ -2,6 +2,8 @@
 // path-tracing mode: load an OBJ, accumulate N frames, write a PFM.
 //   pt_render_cli scene.obj out.pfm [--spp N] [--width W] [--height H] [--cam x y z] [--depth D] [--no-sky]
 //                 [--fallback I] [--light-instance K] [--full-res] [--tonemap] [--device G] [--ao DIST]
+//   pt_render_cli --check-obj scene.obj      (parse only, no GPU: prints mesh / triangle / material counts)
+#include <string>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -10,6 +12,15 @@
 #include "PathTracerHost.h"
 
 int main(int argc, char** argv) {
+  if (argc == 3 && strcmp(argv[1], "--check-obj") == 0) {   // importer only: needs no GPU
+    pth::SceneData sd;
+    std::string err;
+    if (!pth::ImportObj(argv[2], sd, &err)) { fprintf(stderr, "Failed importing scene: %s\n", err.c_str()); return 1; }
+    size_t tris = 0;
+    for (const auto& m : sd.myMeshes) tris += m.myIndexData.size() / 3;
+    printf("meshes %zu triangles %zu materials %zu\n", sd.myMeshes.size(), tris, sd.myMaterials.size());
+    return 0;
+  }
   if (argc < 3) {
     fprintf(stderr, "usage: %s scene.obj out.pfm [--spp N] [--width W] [--height H] [--cam x y z] [--depth D] [--no-sky] "
                     "[--fallback I] [--light-instance K] [--full-res] [--tonemap] [--device G] [--ao DIST]\n", argv[0]);

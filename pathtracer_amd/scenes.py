@@ -25,8 +25,23 @@ def _parse_mtl(path):
     mats, cur = {}, None
     if not os.path.exists(path):
         return mats
+    def resolve(tok, count, what, lineno, required=False):
+        """1-based / negative-relative OBJ index -> 0-based, range-checked (-1 = absent)."""
+        if not tok:
+            if required:
+                raise ValueError(f"{path}:{lineno}: face corner without a position index")
+            return -1
+        try:
+            i = int(tok)
+        except ValueError:
+            raise ValueError(f"{path}:{lineno}: malformed {what} index {tok!r}") from None
+        j = i - 1 if i > 0 else count + i
+        if i == 0 or not 0 <= j < count:
+            raise ValueError(f"{path}:{lineno}: {what} index {i} out of range (have {count})")
+        return j
+
     with open(path) as f:
-        for line in f:
+        for lineno, line in enumerate(f, 1):
             t = line.split()
             if not t or t[0].startswith("#"):
                 continue
@@ -46,8 +61,23 @@ def load_obj(path):
     mtl = {}
     cur = None
     cur_name, cur_mat = "default", None
+    def resolve(tok, count, what, lineno, required=False):
+        """1-based / negative-relative OBJ index -> 0-based, range-checked (-1 = absent)."""
+        if not tok:
+            if required:
+                raise ValueError(f"{path}:{lineno}: face corner without a position index")
+            return -1
+        try:
+            i = int(tok)
+        except ValueError:
+            raise ValueError(f"{path}:{lineno}: malformed {what} index {tok!r}") from None
+        j = i - 1 if i > 0 else count + i
+        if i == 0 or not 0 <= j < count:
+            raise ValueError(f"{path}:{lineno}: {what} index {i} out of range (have {count})")
+        return j
+
     with open(path) as f:
-        for line in f:
+        for lineno, line in enumerate(f, 1):
             t = line.split()
             if not t or t[0].startswith("#"):
                 continue
@@ -72,10 +102,9 @@ def load_obj(path):
                 corners = []
                 for c in t[1:]:
                     p = (c.split("/") + ["", ""])[:3]
-                    vi = int(p[0]); ti = int(p[1]) if p[1] else 0; ni = int(p[2]) if p[2] else 0
-                    corners.append((vi - 1 if vi > 0 else len(pos) + vi,
-                                    (ti - 1 if ti > 0 else len(tex) + ti) if ti else -1,
-                                    (ni - 1 if ni > 0 else len(nrm) + ni) if ni else -1))
+                    corners.append((resolve(p[0], len(pos), "position", lineno, required=True),
+                                    resolve(p[1], len(tex), "texture-coordinate", lineno),
+                                    resolve(p[2], len(nrm), "normal", lineno)))
                 for k in range(1, len(corners) - 1):  # fan triangulation
                     cur[2].append((corners[0], corners[k], corners[k + 1]))
     mat_names = list(mtl.keys())

@@ -108,6 +108,27 @@ def test_obj_reader_roundtrip(tmp_path):
     assert (nm, ni, nmat) == (2, 2, 2) and m[0].num_triangles == 2 and list(ins[1].myTransform)[::5] == [1.0] * 4
 
 
+@pytest.mark.parametrize("face,what", [("f 1 2 9", "out of range"), ("f 0 1 2", "index"), ("f 1 2 -7", "out of range"),
+                                       ("f 1/5 2 3", "out of range"), ("f 1//4 2 3", "out of range"), ("f 1 2 x3", "malformed")])
+def test_obj_readers_reject_bad_face_indices(tmp_path, face, what):
+    """Round-1 review: face indices straight from the file must be range-checked (index 0, beyond the arrays, too
+    negative, malformed tokens) in both readers — an error, never an out-of-bounds read or an uncaught exception."""
+    import subprocess
+    path = tmp_path / "bad.obj"
+    path.write_text("v 0 0 0\nv 1 0 0\nv 0 1 0\nvn 0 0 1\nvt 0 0\n" + face + "\n")
+    with pytest.raises(ValueError):
+        scenes.load_obj(str(path))
+    cli = os.path.join(ROOT, "host", "pt_render_cli")
+    assert os.path.exists(cli), "build host/pt_render_cli first (__graft_entry__.build())"
+    r = subprocess.run([cli, "--check-obj", str(path)], capture_output=True, text=True, timeout=30)
+    assert r.returncode == 1 and "Failed importing scene" in r.stderr and "bad.obj:6" in r.stderr, r.stderr
+    good = tmp_path / "good.obj"
+    good.write_text("v 0 0 0\nv 1 0 0\nv 0 1 0\nvn 0 0 1\nvt 0 0\nf 1/1/1 2/1/1 -1/-1/-1\n")
+    r = subprocess.run([cli, "--check-obj", str(good)], capture_output=True, text=True, timeout=30)
+    assert r.returncode == 0 and "triangles 1" in r.stdout
+    assert scenes.load_obj(str(good)).num_triangles == 1
+
+
 def test_atrium_is_exact_and_deterministic():
     a, b = scenes.atrium(1), scenes.atrium(1)
     assert a.num_triangles == 262144 and len(a.materials) == 24
