@@ -10,7 +10,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libpathtracer_amd.so")
+# PT_AMD_LIB: tuning experiments only (tools/): load another build of the SAME library (e.g. compiled with -DPT_EXP_*)
+LIB_PATH = os.environ.get("PT_AMD_LIB") or os.path.join(_HERE, "lib", "libpathtracer_amd.so")
 
 PT_OK = 0
 PT_ERR_INVALID_ARG = 1

@@ -183,6 +183,24 @@ struct Traverser {
     const uint32_t rel = __popc(hits & ~(0xFFFFFFFFu << slot));
     const uint4* np = nodes + (size_t)(ng.x + rel) * PT_NODE_STRIDE_U4;
     const uint4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3], n4 = np[4];
+#ifdef PT_EXP_EXTRA_LOADS   // experiment: the same 16-byte reads again (L1 hits, one landing register): what does an L1 access cost?
+    {
+      typedef unsigned int u4v __attribute__((ext_vector_type(4)));
+      u4v d;
+#if PT_EXP_EXTRA_LOADS == 5
+      asm volatile("global_load_dwordx4 %0, %1, off\n\tglobal_load_dwordx4 %0, %1, off offset:16\n\tglobal_load_dwordx4 %0, %1, off offset:32\n\t"
+                   "global_load_dwordx4 %0, %1, off offset:48\n\tglobal_load_dwordx4 %0, %1, off offset:64\n\ts_waitcnt vmcnt(0)"
+                   : "=&v"(d) : "v"((const void*)np) : "memory");
+#else
+      asm volatile("global_load_dwordx4 %0, %1, off\n\tglobal_load_dwordx4 %0, %1, off offset:16\n\tglobal_load_dwordx4 %0, %1, off offset:32\n\t"
+                   "global_load_dwordx4 %0, %1, off offset:48\n\tglobal_load_dwordx4 %0, %1, off offset:64\n\t"
+                   "global_load_dwordx4 %0, %1, off\n\tglobal_load_dwordx4 %0, %1, off offset:16\n\tglobal_load_dwordx4 %0, %1, off offset:32\n\t"
+                   "global_load_dwordx4 %0, %1, off offset:48\n\tglobal_load_dwordx4 %0, %1, off offset:64\n\ts_waitcnt vmcnt(0)"
+                   : "=&v"(d) : "v"((const void*)np) : "memory");
+#endif
+      asm volatile("" ::"v"(d));
+    }
+#endif
 
     const uint32_t e = n0.w;
     const float sx = __uint_as_float((e & 0xffu) << 23), sy = __uint_as_float(((e >> 8) & 0xffu) << 23),

@@ -68,6 +68,9 @@ inline float pow2_from_biased(uint8_t e) { uint32_t b = (uint32_t)e << 23; float
 
 }  // namespace
 
+static uint32_t* g_visit_hist = nullptr;   // optional: visits per node index (tools/exp_node_hist.py)
+extern "C" void bvh8_set_visit_hist(uint32_t* hist) { g_visit_hist = hist; }
+
 extern "C" int bvh8_walk(const PtBvh8Node* nodes, uint64_t num_nodes, const PtTriRecord* tris, uint64_t num_tris, float scene_mag,
                          const Ray* rays, uint64_t n, Hit* hits, uint64_t* nodes_opened, uint64_t* tris_tested) {
   uint64_t cn = 0, ct = 0;
@@ -98,6 +101,7 @@ extern "C" int bvh8_walk(const PtBvh8Node* nodes, uint64_t num_nodes, const PtTr
         if (ni >= num_nodes) return -1;
         const PtBvh8Node& nd = nodes[ni];
         ++cn;
+        if (g_visit_hist) ++g_visit_hist[ni];
         uint32_t hitmask = 0u;
         for (int s = 0; s < 8; ++s) {
           const uint8_t meta = nd.meta[s];
