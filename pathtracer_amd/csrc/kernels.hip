@@ -137,8 +137,8 @@ __global__ void __launch_bounds__(256) k_extend(const uint4* __restrict__ nodes,
   extern __shared__ uint2 s_stack[];
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   LaneStack stk;
-  stk.lds = s_stack + (size_t)wave * lds_entries * 64u + lane;
-  stk.spill = spill + ((size_t)blockIdx.x * (blockDim.x >> 6) + wave) * spill_entries * 64u + lane;
+  stk.lds = (lds_u2*)s_stack + (size_t)wave * lds_entries * 64u + lane;
+  stk.spill = (glb_u2*)spill + ((size_t)blockIdx.x * (blockDim.x >> 6) + wave) * spill_entries * 64u + lane;
   stk.lds_entries = (int)lds_entries;
   // DEFER: per-lane queue of deferred triangle groups, in LDS behind the stacks of the block's waves
   uint2* dq = s_stack + (size_t)(blockDim.x >> 6) * lds_entries * 64u + (size_t)wave * dq_entries * 64u + lane;
@@ -151,7 +151,9 @@ __global__ void __launch_bounds__(256) k_extend(const uint4* __restrict__ nodes,
 
   uint32_t pool_next = 0u, pool_end = 0u;   // wave-uniform
   bool exhausted = false;                   // wave-uniform
+  bool wave_risky = false;                  // wave-uniform: a lane holds a ray that needs the overflow-safe box test
   bool busy = false;
+  bool unsaved = false;                     // this lane's finished ray still has its hit record in registers
   uint32_t ray_i = 0u;
   Traverser tr;
   uint32_t n_nodes = 0u, n_tris = 0u, n_node_steps = 0u, n_tri_steps = 0u;   // *_steps: wave-level, lane 0 only
@@ -162,6 +164,14 @@ __global__ void __launch_bounds__(256) k_extend(const uint4* __restrict__ nodes,
     const uint32_t n_idle = (uint32_t)__popcll(idle_mask);
     if (n_idle == 64u && exhausted) break;
     if (!exhausted && (n_idle >= fetch_min)) {
+      // Hit records of finished rays are written here, once per refill, by all the lanes that finished since the last
+      // one: a store per finishing lane per iteration costs the memory pipe one wave-instruction each time.
+      if (unsaved) {
+        HitRec hr = tr.best;
+        if (hr.prim == 0xFFFFFFFFu) hr.t = -1.0f;
+        hits[ray_i] = make_float4(hr.t, hr.u, hr.v, __uint_as_float(hr.prim));
+        unsaved = false;
+      }
       if (pool_next >= pool_end) {
         uint32_t base = 0u;
         if (lane == 0u) base = atomicAdd(work_cursor, chunk);
@@ -195,6 +205,7 @@ __global__ void __launch_bounds__(256) k_extend(const uint4* __restrict__ nodes,
         }
         pool_next += take;
       }
+      wave_risky = __ballot(busy && tr.risky) != 0ull;
       if (__ballot(busy) == 0ull) continue;   // nothing to do yet (pool was empty): claim again or finish
     }
 
@@ -204,7 +215,7 @@ __global__ void __launch_bounds__(256) k_extend(const uint4* __restrict__ nodes,
     if (!DEFER) {
       if (busy) {
         if (tr.has_node_work()) {
-          tr.node_step(nodes, stk);
+          tr.node_step(nodes, stk, wave_risky);
           if (COUNT) ++n_nodes;
         } else {
           tr.tg = tr.ng;
@@ -228,10 +239,8 @@ __global__ void __launch_bounds__(256) k_extend(const uint4* __restrict__ nodes,
       if (any_hit && busy && tr.best.prim != 0xFFFFFFFFu) { tr.ng.y = 0u; tr.tg.y = 0u; tr.sp = 0; }
       if (busy && !tr.has_node_work()) {
         if (tr.sp == 0) {
-          HitRec hr = tr.best;
-          if (hr.prim == 0xFFFFFFFFu) hr.t = -1.0f;
-          hits[ray_i] = make_float4(hr.t, hr.u, hr.v, __uint_as_float(hr.prim));
           busy = false;
+          unsaved = true;
         } else {
           --tr.sp;
           tr.ng = stk.get(tr.sp);
@@ -242,7 +251,7 @@ __global__ void __launch_bounds__(256) k_extend(const uint4* __restrict__ nodes,
       // queue and keeps doing box tests; the wave runs a triangle phase only when enough lanes have parked work
       // (or a queue is full), so both phases run with most lanes active.
       if (busy && tr.has_node_work()) {
-        tr.node_step(nodes, stk);
+        tr.node_step(nodes, stk, wave_risky);
         if (COUNT) ++n_nodes;
       }
       const bool pending = busy && (tr.tg.y != 0u || dqn != 0u);
@@ -272,13 +281,16 @@ __global__ void __launch_bounds__(256) k_extend(const uint4* __restrict__ nodes,
           --tr.sp;
           tr.ng = stk.get(tr.sp);
         } else if (dqn == 0u) {
-          HitRec hr = tr.best;
-          if (hr.prim == 0xFFFFFFFFu) hr.t = -1.0f;
-          hits[ray_i] = make_float4(hr.t, hr.u, hr.v, __uint_as_float(hr.prim));
           busy = false;
+          unsaved = true;
         }   // else: only parked triangles left — wait for the wave's next triangle phase
       }
     }
+  }
+  if (unsaved) {   // rays that finished after the last refill
+    HitRec hr = tr.best;
+    if (hr.prim == 0xFFFFFFFFu) hr.t = -1.0f;
+    hits[ray_i] = make_float4(hr.t, hr.u, hr.v, __uint_as_float(hr.prim));
   }
   if (COUNT) {
     atomicAdd(&stats[ST_NODES], (unsigned long long)n_nodes);

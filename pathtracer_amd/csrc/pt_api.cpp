@@ -414,6 +414,9 @@ int pt_scene_create(pt_ctx* ctx, const PtMeshDesc* meshes, uint32_t num_meshes, 
   Bvh8 bvh;
   build_bvh8(fs.tri_verts.data(), fs.num_triangles(), bvh);
 
+  // the traversal kernel addresses nodes and triangle records with 32-bit byte offsets
+  if (bvh.nodes.size() * (size_t)(PT_NODE_STRIDE_U4 * 16) >= (1ull << 32) || bvh.tris.size() * sizeof(PtTriRecord) >= (1ull << 32))
+    return ctx->fail(PT_ERR_UNSUPPORTED, "scene too large: more than 4 GB of BVH nodes or of triangle records (89 M triangles)");
   PT_HIP(hipStreamSynchronize(ctx->stream));
   free_list(ctx->scene_allocs);
   if (ctx->instance_ext) { (void)hipFree(ctx->instance_ext); ctx->instance_ext = nullptr; }

@@ -90,17 +90,27 @@ __device__ __forceinline__ float safe_dir(float d) { return fabsf(d) < 1e-25f ? 
 // Per-lane stack of 8-byte entries: the first `lds_entries` live in LDS ([entry][lane]: lane-contiguous, conflict-free
 // ds_read/write_b64), deeper entries spill to a per-wave global region with the same layout. Typical traversals stay
 // within the LDS part; the spill only bounds the worst case (2 entries per BVH level).
+// The two halves are addressed through pointers that carry their address space (LDS = 3, global = 1): with generic
+// pointers the compiler joins the branches into FLAT loads / stores, and a FLAT access to LDS still travels through the
+// vector-memory pipe (the texture addresser), the kernel's scarcest resource.
+typedef unsigned int pt_u2v __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) pt_u2v lds_u2;
+typedef __attribute__((address_space(1))) pt_u2v glb_u2;
 struct LaneStack {
-  uint2* lds;        // this lane's slot of LDS entry 0
-  uint2* spill;      // this lane's slot of spill entry 0
+  lds_u2* lds;       // this lane's slot of LDS entry 0
+  glb_u2* spill;     // this lane's slot of spill entry 0
   int lds_entries;
   __device__ __forceinline__ void put(int sp, uint2 v) const {
-    if (sp < lds_entries) lds[sp * 64] = v;
-    else spill[(sp - lds_entries) * 64] = v;
+    pt_u2v w;
+    w.x = v.x; w.y = v.y;
+    if (sp < lds_entries) lds[sp * 64] = w;
+    else spill[(sp - lds_entries) * 64] = w;
   }
   __device__ __forceinline__ uint2 get(int sp) const {
-    if (sp < lds_entries) return lds[sp * 64];
-    return spill[(sp - lds_entries) * 64];
+    pt_u2v w;
+    if (sp < lds_entries) w = lds[sp * 64];
+    else w = spill[(sp - lds_entries) * 64];
+    return make_uint2(w.x, w.y);
   }
 };
 
@@ -112,6 +122,7 @@ struct Traverser {
   HitRec best;
   float idx, idy, idz;
   uint32_t oct;       // bit a set <=> direction component a is negative
+  uint32_t oct4;      // oct replicated into the four bytes of a dword
   uint2 ng;           // pending node group: x = child_base, y = hit bits (top 8, by octant priority) | imask
   uint2 tg;           // pending triangle group: x = tri_base, y = triangle bits (low 24)
   int sp;
@@ -124,6 +135,7 @@ struct Traverser {
     const float sdx = safe_dir(r.dx), sdy = safe_dir(r.dy), sdz = safe_dir(r.dz);
     idx = 1.0f / sdx; idy = 1.0f / sdy; idz = 1.0f / sdz;
     oct = (sdx < 0.0f ? 1u : 0u) | (sdy < 0.0f ? 2u : 0u) | (sdz < 0.0f ? 4u : 0u);
+    oct4 = oct * 0x01010101u;
     ng = make_uint2(0u, 0x80000000u);  // root: one pending internal "child" at priority 7 of a group with base 0
     tg = make_uint2(0u, 0u);
     sp = 0;
@@ -148,7 +160,8 @@ struct Traverser {
       const uint32_t ny = negy ? qhy : qly, fy = negy ? qly : qhy;
       const uint32_t nz = negz ? qhz : qlz, fz = negz ? qlz : qhz;
       const uint32_t is_inner4 = (meta4 & (meta4 << 1)) & 0x10101010u;
-      const uint32_t inner_mask4 = (is_inner4 >> 4) * 0xffu;
+      const uint32_t inner1 = is_inner4 >> 4;                   // 0x01 in every byte of an internal child
+      const uint32_t inner_mask4 = (inner1 << 8) - inner1;        // x 255 without the quarter-rate integer multiply
       const uint32_t bit_index4 = (meta4 ^ (oct4 & inner_mask4)) & 0x1f1f1f1fu;
       const uint32_t child_bits4 = (meta4 >> 5) & 0x07070707u;
 #pragma unroll
@@ -174,15 +187,31 @@ struct Traverser {
 
   // Pops the nearest pending internal child, fetches its 80-byte node (5 x 128-bit loads) and intersects the 8
   // quantised child boxes.
-  __device__ __forceinline__ void node_step(const uint4* __restrict__ nodes, const LaneStack& stk) {
+  // wave_risky (wave-uniform): some lane of the wave holds a ray flagged `risky` (refreshed at every refill).
+  __device__ __forceinline__ void node_step(const uint4* __restrict__ nodes, const LaneStack& stk, bool wave_risky) {
     const uint32_t hits = ng.y;
     const int b = 31 - __clz((int)hits);
     ng.y &= ~(1u << b);
     if (ng.y > 0x00FFFFFFu) { stk.put(sp, ng); ++sp; }
     const uint32_t slot = ((uint32_t)b - 24u) ^ oct;
     const uint32_t rel = __popc(hits & ~(0xFFFFFFFFu << slot));
-    const uint4* np = nodes + (size_t)(ng.x + rel) * PT_NODE_STRIDE_U4;
+    // byte offset in 32 bits (pt_scene_create rejects BVHs beyond 4 GB of nodes): x80 as shift-adds, base stays scalar
+    const uint32_t ni = ng.x + rel;
+#if PT_NODE_STRIDE_U4 == 5
+    const uint32_t noff = ((ni << 2) + ni) << 4;
+#else
+    const uint32_t noff = ni * (PT_NODE_STRIDE_U4 * 16u);
+#endif
+    const uint4* np = (const uint4*)((const char*)nodes + noff);
     const uint4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3], n4 = np[4];
+#ifdef PT_EXP_EXTRA_VALU   // experiment: N more full-rate vector instructions per node step: what does a VALU instruction cost?
+    {
+      float d = __uint_as_float(ng.x);
+#pragma unroll
+      for (int k = 0; k < PT_EXP_EXTRA_VALU; ++k) asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(d));
+      asm volatile("" ::"v"(d));
+    }
+#endif
 #ifdef PT_EXP_EXTRA_LOADS   // experiment: the same 16-byte reads again (L1 hits, one landing register): what does an L1 access cost?
     {
       typedef unsigned int u4v __attribute__((ext_vector_type(4)));
@@ -207,13 +236,12 @@ struct Traverser {
                 sz = __uint_as_float(((e >> 16) & 0xffu) << 23);
     const float px = __uint_as_float(n0.x) - ray.ox, py = __uint_as_float(n0.y) - ray.oy, pz = __uint_as_float(n0.z) - ray.oz;
     const bool negx = (oct & 1u) != 0u, negy = (oct & 2u) != 0u, negz = (oct & 4u) != 0u;
-    const uint32_t oct4 = oct * 0x01010101u;
     uint32_t hitmask = 0u;
     // Fast form: t = q * (2^e / d) + (p - o) / d, one FMA per plane. Its two terms can overflow fp32 although their sum
     // is small (|scene coordinate| / |d| > ~1e37: astronomically large scenes, or near-axis-parallel rays in large
     // ones); such rays (flagged once, at init) take the safe form t = (q * 2^e + (p - o)) / d, where only a genuinely
     // huge distance overflows, with the right sign. The wave-level test keeps the safe form out of ordinary waves.
-    if (__ballot(risky) != 0ull && risky) {
+    if (wave_risky && risky) {
       child_tests<true>(n1, n2, n3, n4, sx, sy, sz, px, py, pz, negx, negy, negz, oct4, hitmask);
     } else {
       child_tests<false>(n1, n2, n3, n4, sx * idx, sy * idy, sz * idz, px * idx, py * idy, pz * idz, negx, negy, negz, oct4, hitmask);
@@ -228,7 +256,8 @@ struct Traverser {
   __device__ __forceinline__ void tri_step(const uint4* __restrict__ tris) {
     const int i = __ffs((int)tg.y) - 1;
     tg.y &= tg.y - 1u;
-    const uint4* tp = tris + (size_t)(tg.x + (uint32_t)i) * 3;
+    const uint32_t ti = tg.x + (uint32_t)i;
+    const uint4* tp = (const uint4*)((const char*)tris + (((ti << 1) + ti) << 4));   // x48, 32-bit offset (< 4 GB of triangle records)
     const uint4 q0 = tp[0], q1 = tp[1], q2 = tp[2];
     tt.test(q0, q1, q2, ray.tmin, best);
   }
