@@ -18,6 +18,7 @@ struct DeviceScene {
   const float4* instance_mat4 = nullptr; // materials[instance_material[i]] per instance
   const float4* instance_ext = nullptr;  // material extension per instance (roughness, metallic, pattern scale, pattern | ggx << 8); null = none
   float scene_mag = 0.0f;              // largest |coordinate| of the active triangles (overflow guard of the box test)
+  uint32_t num_nodes = 0;              // BVH8 nodes in `nodes`
   uint32_t stack_entries = 0;          // stack entries per lane the traversal may need (2 per BVH level + 2)
   uint2* spill = nullptr;              // global spill region of the per-lane stacks: [wave][entry][lane]
 };
@@ -68,9 +69,11 @@ struct LaunchCfg {
   int stream_blocks = 2048;   // grid cap of the grid-stride kernels
   uint32_t fetch_min = 16;    // extend: refill idle lanes once this many of the 64 are idle
   uint32_t postpone_pct = 50; // extend: postpone triangle tests while fewer than this % of busy lanes have any
+  uint32_t continue_pct = 25; // extend (deferred schedule): a triangle phase goes on while at least this % of busy lanes have work
   int extend_blocks_per_cu = 0; // 0 = from the occupancy query
-  uint32_t lds_stack_entries = 8; // per-lane stack entries kept in LDS; deeper entries spill to global memory
+  uint32_t lds_stack_entries = 6; // per-lane stack entries kept in LDS; deeper entries spill to global memory
   uint32_t defer_entries = 4;     // >0: deferred-triangle schedule with this many parked groups per lane
+  uint32_t top_nodes = 73;        // nodes of the tree's top (breadth-first order: 1 + 8 + 64) kept in LDS by every extend block
 };
 
 void launch_transmittance_lut(const PtAtmosphere& atm, uint2* lut, hipStream_t s);
@@ -93,7 +96,7 @@ void launch_resolve(const WavefrontBuffers& wb, float4* accum, uint32_t w, uint3
 void launch_add(float4* dst, const float4* src, uint64_t n, hipStream_t s);   // dst[i] += src[i]
 void launch_set_count(uint32_t* counter, uint32_t value, hipStream_t s);
 void launch_debug_eval(int fn, const PtRtConsts& c, const uint2* lut, const float4* skyview, const float* in, uint64_t n, float* out, hipStream_t s);
-size_t extend_lds_bytes(uint32_t stack_entries);
-int extend_occupancy_blocks(uint32_t lds_entries_total, bool defer);
+size_t extend_lds_bytes(uint32_t lds_entries_total, uint32_t top_nodes);
+int extend_occupancy_blocks(uint32_t lds_entries_total, uint32_t top_nodes, bool defer);
 
 }  // namespace pt

@@ -131,7 +131,7 @@ __global__ void __launch_bounds__(256) k_extend(const uint4* __restrict__ nodes,
                                                 float4* __restrict__ hits, const uint32_t* __restrict__ count_ptr,
                                                 uint32_t* __restrict__ work_cursor, unsigned long long* __restrict__ stats,
                                                 uint32_t lds_entries, uint32_t spill_entries, uint2* __restrict__ spill, uint32_t stride, uint32_t fetch_min,
-                                                uint32_t postpone_pct, uint32_t dq_entries, uint32_t any_hit, float scene_mag) {
+                                                uint32_t postpone_pct, uint32_t dq_entries, uint32_t any_hit, float scene_mag, uint32_t top_nodes, uint32_t continue_pct) {
   // any_hit (wave-uniform): a ray ends at the first accepted intersection (occlusion queries: Ao.hlsl's ClosestHitAo
   // only reports that something was hit). Only "prim != miss" is then defined in the hit record.
   extern __shared__ uint2 s_stack[];
@@ -143,6 +143,15 @@ __global__ void __launch_bounds__(256) k_extend(const uint4* __restrict__ nodes,
   // DEFER: per-lane queue of deferred triangle groups, in LDS behind the stacks of the block's waves
   uint2* dq = s_stack + (size_t)(blockDim.x >> 6) * lds_entries * 64u + (size_t)wave * dq_entries * 64u + lane;
   uint32_t dqn = 0u;
+  // the top of the tree (first top_nodes nodes, breadth-first order), copied into LDS once per block
+  lds_u4* s_top = (lds_u4*)((lds_u2*)s_stack + (size_t)(blockDim.x >> 6) * (lds_entries + dq_entries) * 64u);
+  for (uint32_t i = threadIdx.x; i < top_nodes * PT_NODE_STRIDE_U4; i += blockDim.x) {
+    const uint4 v = nodes[i];
+    pt_u4v w;
+    w.x = v.x; w.y = v.y; w.z = v.z; w.w = v.w;
+    s_top[i] = w;
+  }
+  __syncthreads();
   const uint32_t n = *count_ptr;
   // chunk: large enough to amortise the atomic, small enough to balance the tail (~8 chunks per wave)
   const uint32_t total_waves = gridDim.x * (blockDim.x >> 6);
@@ -215,7 +224,7 @@ __global__ void __launch_bounds__(256) k_extend(const uint4* __restrict__ nodes,
     if (!DEFER) {
       if (busy) {
         if (tr.has_node_work()) {
-          tr.node_step(nodes, stk, wave_risky);
+          tr.node_step(nodes, stk, wave_risky, s_top, top_nodes);
           if (COUNT) ++n_nodes;
         } else {
           tr.tg = tr.ng;
@@ -251,7 +260,7 @@ __global__ void __launch_bounds__(256) k_extend(const uint4* __restrict__ nodes,
       // queue and keeps doing box tests; the wave runs a triangle phase only when enough lanes have parked work
       // (or a queue is full), so both phases run with most lanes active.
       if (busy && tr.has_node_work()) {
-        tr.node_step(nodes, stk, wave_risky);
+        tr.node_step(nodes, stk, wave_risky, s_top, top_nodes);
         if (COUNT) ++n_nodes;
       }
       const bool pending = busy && (tr.tg.y != 0u || dqn != 0u);
@@ -265,7 +274,7 @@ __global__ void __launch_bounds__(256) k_extend(const uint4* __restrict__ nodes,
             const unsigned long long m = __ballot(has);
             if (m == 0ull) break;
             const unsigned long long must = __ballot(has && dqn == dq_entries);
-            if (must == 0ull && (uint32_t)__popcll(m) * 200u < n_busy * postpone_pct) break;   // tail: leave the rest parked
+            if (must == 0ull && (uint32_t)__popcll(m) * 100u < n_busy * continue_pct) break;   // tail: leave the rest parked
             if (COUNT) ++n_tri_steps;
             if (has) {
               tr.tri_step(tris);
@@ -710,12 +719,14 @@ void launch_generate(const PtRtConsts& c, const WavefrontBuffers& wb, uint32_t w
                      wb.counters, w, h, first_sample, n);
 }
 
-size_t extend_lds_bytes(uint32_t lds_entries_total) { return (size_t)lds_entries_total * 64u * sizeof(uint2) * 4u; }
+size_t extend_lds_bytes(uint32_t lds_entries_total, uint32_t top_nodes) {
+  return (size_t)lds_entries_total * 64u * sizeof(uint2) * 4u + (size_t)top_nodes * PT_NODE_STRIDE_U4 * 16u;
+}
 
-int extend_occupancy_blocks(uint32_t lds_entries_total, bool defer) {
+int extend_occupancy_blocks(uint32_t lds_entries_total, uint32_t top_nodes, bool defer) {
   int nb = 0;
-  const hipError_t e = defer ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_extend<false, true>, 256, extend_lds_bytes(lds_entries_total))
-                             : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_extend<false, false>, 256, extend_lds_bytes(lds_entries_total));
+  const hipError_t e = defer ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_extend<false, true>, 256, extend_lds_bytes(lds_entries_total, top_nodes))
+                             : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_extend<false, false>, 256, extend_lds_bytes(lds_entries_total, top_nodes));
   if (e != hipSuccess || nb < 1) nb = 1;
   return nb;
 }
@@ -727,7 +738,9 @@ void launch_extend(const DeviceScene& sc, const float4* ray_o, const float4* ray
     lds_entries = PT_EXTEND_MAX_LDS_ENTRIES - cfg.defer_entries;     // the rest of the stack goes to the spill region
   const uint32_t spill_entries = sc.stack_entries - lds_entries;
   const uint32_t dq = cfg.defer_entries;
-  const size_t lds = extend_lds_bytes(lds_entries + dq);
+  uint32_t top_nodes = sc.num_nodes < cfg.top_nodes ? sc.num_nodes : cfg.top_nodes;
+  while (top_nodes > 0 && extend_lds_bytes(lds_entries + dq, top_nodes) > 160u * 1024u) top_nodes /= 2;   // one CU's LDS
+  const size_t lds = extend_lds_bytes(lds_entries + dq, top_nodes);
   if (lds > 64 * 1024) {   // deep BVHs: opt in to more than the default dynamic-LDS limit. The attribute belongs to the CURRENT
                            // device (one process may drive several, pt_reduce), so it is set on every such launch: no cached flag.
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_extend<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -737,7 +750,7 @@ void launch_extend(const DeviceScene& sc, const float4* ray_o, const float4* ray
   }
 #define PT_LAUNCH_EXTEND(C, D)                                                                                              \
   hipLaunchKernelGGL((k_extend<C, D>), dim3(cfg.extend_blocks), dim3(256), lds, s, sc.nodes, sc.tris, ray_o, ray_d, hits, count, \
-                     work_cursor, stats, lds_entries, spill_entries, sc.spill, stride, cfg.fetch_min, cfg.postpone_pct, dq, any_hit ? 1u : 0u, sc.scene_mag)
+                     work_cursor, stats, lds_entries, spill_entries, sc.spill, stride, cfg.fetch_min, cfg.postpone_pct, dq, any_hit ? 1u : 0u, sc.scene_mag, top_nodes, cfg.continue_pct)
   if (dq > 0) {
     if (count_traversal) PT_LAUNCH_EXTEND(true, true); else PT_LAUNCH_EXTEND(false, true);
   } else {

@@ -217,7 +217,7 @@ int extend_grid(pt_ctx* ctx) {
   int per_cu = ctx->cfg.extend_blocks_per_cu;
   if (per_cu <= 0) {
     const uint32_t lds_entries = std::min<uint32_t>(std::min(ctx->ds.stack_entries, ctx->cfg.lds_stack_entries) + ctx->cfg.defer_entries, PT_EXTEND_MAX_LDS_ENTRIES);
-    per_cu = std::max(1, std::min(8, extend_occupancy_blocks(lds_entries, ctx->cfg.defer_entries > 0)));
+    per_cu = std::max(1, std::min(8, extend_occupancy_blocks(lds_entries, std::min<uint32_t>(ctx->cfg.top_nodes, ctx->ds.num_nodes), ctx->cfg.defer_entries > 0)));
   }
   return ctx->cfg.num_cus * per_cu;
 }
@@ -394,6 +394,16 @@ int pt_set_option(pt_ctx* ctx, int option, int64_t value) {
       if (ctx->has_scene)
         ctx->cfg.extend_blocks = extend_grid(ctx);
       return PT_OK;
+    case PT_OPT_EXTEND_CONTINUE_PCT:
+      if (value < 0 || value > 100) return ctx->fail(PT_ERR_INVALID_ARG, "continue_pct must be 0..100");
+      ctx->cfg.continue_pct = (uint32_t)value;
+      return PT_OK;
+    case PT_OPT_EXTEND_TOP_NODES:
+      if (value < 0 || value > 1024) return ctx->fail(PT_ERR_INVALID_ARG, "top nodes kept in LDS must be 0..1024");
+      ctx->cfg.top_nodes = (uint32_t)value;
+      if (ctx->has_scene)
+        ctx->cfg.extend_blocks = extend_grid(ctx);
+      return PT_OK;
     case PT_OPT_EXTEND_BLOCKS_PER_CU:
       if (value < 0 || value > 16) return ctx->fail(PT_ERR_INVALID_ARG, "blocks per CU must be 0..16");
       ctx->cfg.extend_blocks_per_cu = (int)value;
@@ -467,6 +477,7 @@ int pt_scene_create(pt_ctx* ctx, const PtMeshDesc* meshes, uint32_t num_meshes, 
   ctx->ds.instance_material = d_im;
   ctx->ds.materials = d_mat;
   ctx->ds.instance_mat4 = d_imat;
+  ctx->ds.num_nodes = (uint32_t)bvh.nodes.size();
   for (int a = 0; a < 3; ++a) ctx->ds.scene_mag = std::max(ctx->ds.scene_mag, std::max(std::fabs(bvh.lo[a]), std::fabs(bvh.hi[a])));
   ctx->ds.stack_entries = 2 * bvh.max_depth + 2;   // <=1 sibling group + <=1 postponed triangle group per level
   if (bvh.max_depth > 62)

@@ -95,6 +95,8 @@ __device__ __forceinline__ float safe_dir(float d) { return fabsf(d) < 1e-25f ? 
 // vector-memory pipe (the texture addresser), the kernel's scarcest resource.
 typedef unsigned int pt_u2v __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) pt_u2v lds_u2;
+typedef unsigned int pt_u4v __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) pt_u4v lds_u4;
 typedef __attribute__((address_space(1))) pt_u2v glb_u2;
 struct LaneStack {
   lds_u2* lds;       // this lane's slot of LDS entry 0
@@ -188,7 +190,10 @@ struct Traverser {
   // Pops the nearest pending internal child, fetches its 80-byte node (5 x 128-bit loads) and intersects the 8
   // quantised child boxes.
   // wave_risky (wave-uniform): some lane of the wave holds a ray flagged `risky` (refreshed at every refill).
-  __device__ __forceinline__ void node_step(const uint4* __restrict__ nodes, const LaneStack& stk, bool wave_risky) {
+  // top / top_nodes: the first top_nodes nodes of the array (its breadth-first top levels) also sit in LDS; lanes whose
+  // node is among them read it there and stay off the vector-memory pipe.
+  __device__ __forceinline__ void node_step(const uint4* __restrict__ nodes, const LaneStack& stk, bool wave_risky,
+                                            const lds_u4* top, uint32_t top_nodes) {
     const uint32_t hits = ng.y;
     const int b = 31 - __clz((int)hits);
     ng.y &= ~(1u << b);
@@ -203,7 +208,21 @@ struct Traverser {
     const uint32_t noff = ni * (PT_NODE_STRIDE_U4 * 16u);
 #endif
     const uint4* np = (const uint4*)((const char*)nodes + noff);
-    const uint4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3], n4 = np[4];
+    uint4 n0, n1, n2, n3, n4;
+    if (ni < top_nodes) {
+      const lds_u4* lp = (const lds_u4*)((const __attribute__((address_space(3))) char*)top + noff);
+      const pt_u4v a0 = lp[0], a1 = lp[1], a2 = lp[2], a3 = lp[3], a4 = lp[4];
+      n0 = make_uint4(a0.x, a0.y, a0.z, a0.w); n1 = make_uint4(a1.x, a1.y, a1.z, a1.w); n2 = make_uint4(a2.x, a2.y, a2.z, a2.w);
+      n3 = make_uint4(a3.x, a3.y, a3.z, a3.w); n4 = make_uint4(a4.x, a4.y, a4.z, a4.w);
+    } else {
+#ifdef PT_EXP_SPLIT_LOADS   // experiment: first 16 bytes alone (brings the line in), the other 64 once it has landed
+      n0 = np[0];
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      n1 = np[1]; n2 = np[2]; n3 = np[3]; n4 = np[4];
+#else
+      n0 = np[0]; n1 = np[1]; n2 = np[2]; n3 = np[3]; n4 = np[4];
+#endif
+    }
 #ifdef PT_EXP_EXTRA_VALU   // experiment: N more full-rate vector instructions per node step: what does a VALU instruction cost?
     {
       float d = __uint_as_float(ng.x);

@@ -258,7 +258,7 @@ def test_deep_hierarchy_with_every_stack_configuration(ctx, oracle):
             assert np.array_equal(got["prim"], ref["prim"]), (lds, defer)
             assert np.array_equal(got["t"].view(np.uint32), ref["t"].view(np.uint32)), (lds, defer)
     finally:
-        ctx.set_option(api.PT_OPT_EXTEND_LDS_STACK, 8)
+        ctx.set_option(api.PT_OPT_EXTEND_LDS_STACK, 6)
         ctx.set_option(api.PT_OPT_EXTEND_DEFER, 4)
 
 
@@ -697,7 +697,7 @@ def test_extend_schedule_options_never_change_hits(ctx, oracle, fetch_min, postp
     rays = random_rays(31, 150000, list(info.bounds_min), list(info.bounds_max), tmin=0.001, tmax=10000.0)
     ref = osc.trace_rays(rays)
     opts = ((api.PT_OPT_EXTEND_FETCH_MIN, fetch_min, 16), (api.PT_OPT_EXTEND_POSTPONE_PCT, postpone, 50),
-            (api.PT_OPT_EXTEND_BLOCKS_PER_CU, blocks, 0), (api.PT_OPT_EXTEND_LDS_STACK, lds_stack, 8),
+            (api.PT_OPT_EXTEND_BLOCKS_PER_CU, blocks, 0), (api.PT_OPT_EXTEND_LDS_STACK, lds_stack, 6),
             (api.PT_OPT_EXTEND_DEFER, defer, 4))
     try:
         for o, v, _ in opts:
