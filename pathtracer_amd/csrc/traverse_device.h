@@ -162,8 +162,12 @@ struct Traverser {
       const uint32_t ny = negy ? qhy : qly, fy = negy ? qly : qhy;
       const uint32_t nz = negz ? qhz : qlz, fz = negz ? qlz : qhz;
       const uint32_t is_inner4 = (meta4 & (meta4 << 1)) & 0x10101010u;
-      const uint32_t inner1 = is_inner4 >> 4;                   // 0x01 in every byte of an internal child
-      const uint32_t inner_mask4 = (inner1 << 8) - inner1;        // x 255 without the quarter-rate integer multiply
+      // 0b111 in every byte of an internal child (only the three octant bits are ever masked). Two shift-or instructions,
+      // pinned as asm: the compiler folds every C form of this back into a quarter-rate v_mul_lo_u32.
+      const uint32_t inner1 = is_inner4 >> 4;
+      uint32_t inner3, inner_mask4;
+      asm("v_lshl_or_b32 %0, %1, 1, %1" : "=v"(inner3) : "v"(inner1));
+      asm("v_lshl_or_b32 %0, %1, 2, %2" : "=v"(inner_mask4) : "v"(inner1), "v"(inner3));
       const uint32_t bit_index4 = (meta4 ^ (oct4 & inner_mask4)) & 0x1f1f1f1fu;
       const uint32_t child_bits4 = (meta4 >> 5) & 0x07070707u;
 #pragma unroll
@@ -203,7 +207,9 @@ struct Traverser {
     // byte offset in 32 bits (pt_scene_create rejects BVHs beyond 4 GB of nodes): x80 as shift-adds, base stays scalar
     const uint32_t ni = ng.x + rel;
 #if PT_NODE_STRIDE_U4 == 5
-    const uint32_t noff = ((ni << 2) + ni) << 4;
+    uint32_t noff;
+    asm("v_lshl_add_u32 %0, %1, 2, %1" : "=v"(noff) : "v"(ni));   // x5 (asm: the compiler turns shift-adds into v_mul_lo_u32)
+    noff <<= 4;
 #else
     const uint32_t noff = ni * (PT_NODE_STRIDE_U4 * 16u);
 #endif
@@ -276,7 +282,9 @@ struct Traverser {
     const int i = __ffs((int)tg.y) - 1;
     tg.y &= tg.y - 1u;
     const uint32_t ti = tg.x + (uint32_t)i;
-    const uint4* tp = (const uint4*)((const char*)tris + (((ti << 1) + ti) << 4));   // x48, 32-bit offset (< 4 GB of triangle records)
+    uint32_t toff;
+    asm("v_lshl_add_u32 %0, %1, 1, %1" : "=v"(toff) : "v"(ti));   // x3, then x16: 32-bit offset (< 4 GB of triangle records)
+    const uint4* tp = (const uint4*)((const char*)tris + (toff << 4));
     const uint4 q0 = tp[0], q1 = tp[1], q2 = tp[2];
     tt.test(q0, q1, q2, ray.tmin, best);
   }
