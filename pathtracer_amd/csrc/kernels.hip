@@ -312,8 +312,11 @@ __global__ void __launch_bounds__(256) k_extend(const uint4* __restrict__ nodes,
 }
 
 // ------------------------------------------------------------------------------------------------ shade
+#ifndef PT_SHADE_MIN_WAVES
+#define PT_SHADE_MIN_WAVES 1
+#endif
 template <bool EXT>
-__global__ void __launch_bounds__(PT_SHADE_THREADS) k_shade(PtRtConsts c, DeviceScene sc, const float4* __restrict__ ray_o_in,
+__global__ void __launch_bounds__(PT_SHADE_THREADS, PT_SHADE_MIN_WAVES) k_shade(PtRtConsts c, DeviceScene sc, const float4* __restrict__ ray_o_in,
                                                const float4* __restrict__ ray_d_in, const uint32_t* __restrict__ qid_in,
                                                const float4* __restrict__ hits, float4* __restrict__ st_T,
                                                float4* __restrict__ st_L, float4* __restrict__ ray_o_out,
