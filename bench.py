@@ -28,6 +28,7 @@ VALU_PEAK_GINSTR = 1228.8      # wave64 VALU instructions/s: 256 CUs x 4 SIMD32 
 NODE_BYTES, TRI_BYTES, RAY_IO_BYTES = 80, 48, 48   # B_ray = 80*N_node + 48*N_tri + 48
 NODE_FLOP, TRI_FLOP = 176.0, 45.0                  # F_ray = 8*22*N_node + 45*N_tri
 FP32_PEAK_TFLOPS = 157.3                           # MI355X_MICROARCH.md: peak fp32 vector
+L1_PEAK_GBS = 39321.6                              # vector L1 return path: 64 B/clk/CU x 256 CUs x 2.4 GHz
 PMC_ROUND = "r02"                                  # profiles/<round>/pmc_traffic.json: counters of THIS build
 DEF_DEFER, DEF_POSTPONE = 4, 50                   # the library defaults (csrc/kernels.h LaunchCfg)
 
@@ -243,6 +244,14 @@ def main():
             valu = {"wave_instr_per_launch": pmc["extend_valu_wave_instr_per_launch"],
                     "lanes_active_per_instr": pmc.get("extend_lanes_active_per_valu_instr"),
                     "achieved_ginstr_per_s": round(g, 1), "peak_ginstr_per_s": VALU_PEAK_GINSTR, "frac": round(g / VALU_PEAK_GINSTR, 4)}
+        # vector-memory pipe (L1 -> VGPR return path): every wave-level load moves 64 lanes x its width whatever the lanes
+        # do with it; steps of the shipped schedule (COUNT pass) x loads per step (node: 5 x 16 B, triangle: 16+12+12 B)
+        l1_bytes = (ship.node_wave_steps * 64.0 * 80.0 + ship.tri_wave_steps * 64.0 * 40.0) / max(1, ship.rays) * se.rays / launches
+        vmem = {"l1_return_bytes_per_launch": round(l1_bytes, 1), "achieved_gbs": round(l1_bytes / launch_s / 1e9, 1),
+                "peak_gbs": L1_PEAK_GBS, "frac": round(l1_bytes / launch_s / 1e9 / L1_PEAK_GBS, 4),
+                "ta_busy_frac": pmc.get("extend_ta_busy_frac") if pmc else None, "td_busy_frac": pmc.get("extend_td_busy_frac") if pmc else None,
+                "ta_stalled_by_cache_frac": pmc.get("extend_ta_stalled_by_tc_frac") if pmc else None,
+                "note": "64 B/clk/CU x 256 CUs x 2.4 GHz; busy fractions from the PMC profile (cycles with work queued, stalls on cache misses included)"}
         # The binding roof is the larger measured fraction: VALU issue (PMC instruction count / live launch time) or
         # fabric-side traffic against the HBM peak. Without a PMC profile of this build + workload the line falls back to
         # the algorithmic fp32 rate against the vector peak (never above 1).
@@ -257,7 +266,7 @@ def main():
                    "basis": "algorithmic fp32 flops (no PMC profile committed for this workload/size/build)"}
         roofline = {
             **top, "kernel": "k_extend", "traffic": traffic,
-            "hbm_algorithmic": hbm, "fabric": fabric, "valu_issue": valu, "flops_algorithmic": flops,
+            "hbm_algorithmic": hbm, "fabric": fabric, "valu_issue": valu, "vmem_pipe": vmem, "flops_algorithmic": flops,
             "nodes_per_ray": round(nodes_per_ray, 3), "tris_per_ray": round(tris_per_ray, 3),
             "shipped_schedule": {"nodes_per_ray": round(ship.nodes_visited / max(1, ship.rays), 3),
                                  "tris_per_ray": round(ship.tris_tested / max(1, ship.rays), 3),

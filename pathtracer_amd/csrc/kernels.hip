@@ -358,10 +358,11 @@ __global__ void __launch_bounds__(PT_SHADE_THREADS, PT_SHADE_MIN_WAVES) k_shade(
       } else {
         ++shaded_local;
         // ---- ClosestHit: PathTracing.hlsl:16-38, loaders Common.hlsl:75-127 ----
-        const uint4 pd = sc.prim_data[prim];                 // LoadTriangleIndices + InstanceID()
-        const uint32_t instanceId = pd.w;
-        const float4 mat = sc.instance_mat4[instanceId];     // LoadInstanceData + LoadMaterialData, pre-resolved per instance
-        const float4 n0 = sc.vertex_normal[pd.x], n1 = sc.vertex_normal[pd.y], n2 = sc.vertex_normal[pd.z];
+        // LoadTriangleIndices + InstanceID() + LoadInstanceData + LoadMaterialData + 3 x LoadVertexData, resolved at
+        // upload into one 64-byte row per triangle: one dependent fetch instead of a chain of three
+        const float4* ps = sc.prim_shade + (size_t)prim * 4;
+        const float4 n0 = ps[0], n1 = ps[1], n2 = ps[2], mat = ps[3];
+        const uint32_t instanceId = __float_as_uint(n0.w);
         const float bu = hr.y, bv = hr.z;                    // attrib.bary (DXR meaning, Q5)
         const float baryZ = 1.0f - (bu + bv);
         v3 hitNormal = bu * mk3(n0.x, n0.y, n0.z) + bv * mk3(n1.x, n1.y, n1.z) + baryZ * mk3(n2.x, n2.y, n2.z);
@@ -373,6 +374,7 @@ __global__ void __launch_bounds__(PT_SHADE_THREADS, PT_SHADE_MIN_WAVES) k_shade(
           const float4 ext = sc.instance_ext[instanceId];
           const uint32_t bits = __float_as_uint(ext.w);
           if (bits & 0xffu) {
+            const uint4 pd = sc.prim_data[prim];
             const float2 t0 = sc.vertex_uv[pd.x], t1 = sc.vertex_uv[pd.y], t2 = sc.vertex_uv[pd.z];
             v2 uv;   // LoadInterpolatedVertexData weights (Common.hlsl:121-126), as for the normal
             uv.x = bu * t0.x + bv * t1.x + baryZ * t2.x;
@@ -555,8 +557,8 @@ __global__ void __launch_bounds__(256) k_ao_rays(PtRtConsts c, DeviceScene sc, c
   for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gridDim.x * blockDim.x) {
     const uint32_t pid = qid[t / PT_AO_RAYS], i = t % PT_AO_RAYS;
     const float4 ro = ray_o[pid], rd = ray_d[pid], hr = hits[pid];
-    const uint4 pd = sc.prim_data[__float_as_uint(hr.w)];
-    const float4 n0 = sc.vertex_normal[pd.x], n1 = sc.vertex_normal[pd.y], n2 = sc.vertex_normal[pd.z];
+    const float4* ps = sc.prim_shade + (size_t)__float_as_uint(hr.w) * 4;
+    const float4 n0 = ps[0], n1 = ps[1], n2 = ps[2];
     const float bu = hr.y, bv = hr.z;
     const float baryZ = 1.0f - (bu + bv);
     const v3 hitNormal = bu * mk3(n0.x, n0.y, n0.z) + bv * mk3(n1.x, n1.y, n1.z) + baryZ * mk3(n2.x, n2.y, n2.z);

@@ -434,7 +434,7 @@ int pt_scene_create(pt_ctx* ctx, const PtMeshDesc* meshes, uint32_t num_meshes, 
   ctx->ds = DeviceScene();
 
   uint4 *d_nodes, *d_tris, *d_prim;
-  float4 *d_vn, *d_mat, *d_imat;
+  float4 *d_vn, *d_mat, *d_imat, *d_ps;
   float2* d_uv;
   uint32_t* d_im;
   if ((rc = dev_alloc(ctx, &d_nodes, bvh.nodes.size() * PT_NODE_STRIDE_U4, &ctx->scene_allocs))) return rc;
@@ -445,6 +445,7 @@ int pt_scene_create(pt_ctx* ctx, const PtMeshDesc* meshes, uint32_t num_meshes, 
   if ((rc = dev_alloc(ctx, &d_im, fs.instance_material.size(), &ctx->scene_allocs))) return rc;
   if ((rc = dev_alloc(ctx, &d_mat, (size_t)num_materials, &ctx->scene_allocs))) return rc;
   if ((rc = dev_alloc(ctx, &d_imat, fs.instance_material.size(), &ctx->scene_allocs))) return rc;
+  if ((rc = dev_alloc(ctx, &d_ps, (size_t)fs.num_triangles() * 4, &ctx->scene_allocs))) return rc;
   // LoadInstanceData + LoadMaterialData (Common.hlsl:75-100) resolved once per instance: one gather per hit, not two
   std::vector<float> inst_mat(fs.instance_material.size() * 4);
   for (size_t i = 0; i < fs.instance_material.size(); ++i)
@@ -468,6 +469,23 @@ int pt_scene_create(pt_ctx* ctx, const PtMeshDesc* meshes, uint32_t num_meshes, 
   PT_HIP(up(d_im, fs.instance_material.data(), fs.instance_material.size() * 4));
   PT_HIP(up(d_mat, fs.materials.data(), fs.materials.size() * 4));
   PT_HIP(up(d_imat, inst_mat.data(), inst_mat.size() * 4));
+  {
+    // ClosestHit record per triangle (PathTracing.hlsl:16-38 reads instance -> material, 3 indices, 3 x VertexData: four
+    // dependent fetches; here they are resolved at upload into one 64-byte row)
+    const size_t nt = fs.num_triangles();
+    std::vector<float> rows(nt * 16);
+    for (size_t t = 0; t < nt; ++t) {
+      const uint32_t inst = fs.prim_data[4 * t + 3];
+      float* r = &rows[16 * t];
+      for (int k = 0; k < 3; ++k) {
+        memcpy(r + 4 * k, &fs.vertex_normal[4 * (size_t)fs.prim_data[4 * t + k]], 12);
+        r[4 * k + 3] = 0.0f;
+      }
+      memcpy(r + 3, &inst, 4);
+      memcpy(r + 12, &inst_mat[4 * (size_t)inst], 16);
+    }
+    PT_HIP(up(d_ps, rows.data(), rows.size() * 4));
+  }
 
   ctx->ds.nodes = d_nodes;
   ctx->ds.tris = d_tris;
@@ -477,6 +495,7 @@ int pt_scene_create(pt_ctx* ctx, const PtMeshDesc* meshes, uint32_t num_meshes, 
   ctx->ds.instance_material = d_im;
   ctx->ds.materials = d_mat;
   ctx->ds.instance_mat4 = d_imat;
+  ctx->ds.prim_shade = d_ps;
   ctx->ds.num_nodes = (uint32_t)bvh.nodes.size();
   for (int a = 0; a < 3; ++a) ctx->ds.scene_mag = std::max(ctx->ds.scene_mag, std::max(std::fabs(bvh.lo[a]), std::fabs(bvh.hi[a])));
   ctx->ds.stack_entries = 2 * bvh.max_depth + 2;   // <=1 sibling group + <=1 postponed triangle group per level

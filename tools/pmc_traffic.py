@@ -29,11 +29,27 @@ e = out["kernels"].get("pt::k_extend")
 out["extend_bytes_per_launch"] = e["bytes_per_launch_corrected"] if e else None
 out["extend_valu_wave_instr_per_launch"] = e["valu_wave_instr_per_launch"] if e else None
 out["extend_lanes_active_per_valu_instr"] = e["lanes_active_per_valu_instr"] if e else None
+# vector-memory pipe of the extend kernel: TA / TD busy cycles (summed over the 256 CUs) against the dispatch's cycles
+# (GRBM_GUI_ACTIVE is summed over the 8 XCDs), wave-level load instructions per launch
+ke = next((k for k in acc if k.startswith("pt::k_extend")), None)
+if ke and acc[ke].get("GRBM_GUI_ACTIVE") and acc[ke].get("TA_TA_BUSY_sum"):
+    cyc = acc[ke]["GRBM_GUI_ACTIVE"] / calls[ke]["GRBM_GUI_ACTIVE"] / 8.0
+    out["extend_cycles_per_launch"] = round(cyc)
+    out["extend_ta_busy_frac"] = round(acc[ke]["TA_TA_BUSY_sum"] / calls[ke]["TA_TA_BUSY_sum"] / 256.0 / cyc, 4)
+    out["extend_td_busy_frac"] = round(acc[ke]["TD_TD_BUSY_sum"] / calls[ke]["TD_TD_BUSY_sum"] / 256.0 / cyc, 4)
+    out["extend_ta_stalled_by_tc_frac"] = round(acc[ke]["TA_ADDR_STALLED_BY_TC_CYCLES_sum"] / calls[ke]["TA_ADDR_STALLED_BY_TC_CYCLES_sum"] / 256.0 / cyc, 4)
+    out["extend_vmem_rd_wave_instr_per_launch"] = round(acc[ke]["SQ_INSTS_VMEM_RD"] / calls[ke]["SQ_INSTS_VMEM_RD"])
+    out["extend_salu_instr_per_launch"] = round(acc[ke]["SQ_INSTS_SALU"] / calls[ke]["SQ_INSTS_SALU"])
+    out["extend_l2_hit_rate"] = round(acc[ke]["TCC_HIT_sum"] / (acc[ke]["TCC_HIT_sum"] + acc[ke]["TCC_MISS_sum"]), 4)
+for extra in sys.argv[7:]:          # optional key=value pairs: material_ext=1 russian_roulette=1
+    k, v = extra.split("=")
+    out[k] = int(v)
 out["note"] = ("rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE (separate passes), mean over the k_extend launches of bench.py --steps 2; "
                "bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024, the gfx950 doubling of FETCH_SIZE applied although the BVH gathers are "
                "not the calibrated streaming pattern; fabric-side, Infinity-Cache hits included")
 path = "profiles/r02/pmc_traffic.json"
 cur = json.load(open(path)) if os.path.exists(path) else []
-cur = [c for c in cur if (c["workload"], c["width"], c["height"], c["spp_per_step"], c["depth"]) != (workload, w, h, spp, depth)] + [out]
+key = lambda c: (c["workload"], c["width"], c["height"], c["spp_per_step"], c["depth"], c.get("material_ext", 0), c.get("russian_roulette", 0))
+cur = [c for c in cur if key(c) != key(out)] + [out]
 json.dump(cur, open(path, "w"), indent=1)
 print(json.dumps(out, indent=1))
