@@ -7,6 +7,9 @@
 #include "bvh8.h"
 #include "device_math.h"
 
+#ifndef PT_MIX_FMA
+#define PT_MIX_FMA 1   // 1 = plane bytes enter the box test as binary16 denormals through v_fma_mix_f32 (see child_tests)
+#endif
 #ifndef PT_NODE_STRIDE_U4
 #define PT_NODE_STRIDE_U4 5   // device stride of a BVH node in 16-byte units (5 = packed 80-byte nodes)
 #endif
@@ -142,7 +145,8 @@ struct Traverser {
     tg = make_uint2(0u, 0u);
     sp = 0;
     const float reach = fmaxf(scene_mag, fmaxf(fabsf(r.ox), fmaxf(fabsf(r.oy), fabsf(r.oz))));
-    risky = !(reach * fmaxf(fabsf(idx), fmaxf(fabsf(idy), fabsf(idz))) < 1e36f);
+    // 1e36 / 2^24 with PT_MIX_FMA: the fast form's plane coefficient carries an extra factor 2^24
+    risky = !(reach * fmaxf(fabsf(idx), fmaxf(fabsf(idy), fabsf(idz))) < (PT_MIX_FMA ? 5e28f : 1e36f));
   }
 
   __device__ __forceinline__ bool has_node_work() const { return ng.y > 0x00FFFFFFu; }
@@ -170,14 +174,43 @@ struct Traverser {
       asm("v_lshl_or_b32 %0, %1, 2, %2" : "=v"(inner_mask4) : "v"(inner1), "v"(inner3));
       const uint32_t bit_index4 = (meta4 ^ (oct4 & inner_mask4)) & 0x1f1f1f1fu;
       const uint32_t child_bits4 = (meta4 >> 5) & 0x07070707u;
+#if PT_MIX_FMA
+      // Fast form only: the plane bytes go into the FMA as binary16 DENORMALS (a byte q in a 16-bit lane is the half
+      // q * 2^-24; v_fma_mix_f32 widens it exactly), against coefficients pre-scaled by 2^24: q*2^-24 * (a*2^24) + b is
+      // the same real number as q*a + b, rounded once either way, so the bits equal the convert-then-FMA form while two
+      // planes share one byte-permute instead of one conversion each.
+      typedef _Float16 pt_h2 __attribute__((ext_vector_type(2)));
+      pt_h2 hnx[2], hny[2], hnz[2], hfx[2], hfy[2], hfz[2];
+      if (!SAFE) {
+        hnx[0] = __builtin_bit_cast(pt_h2, __builtin_amdgcn_perm(0u, nx, 0x0c010c00u)); hnx[1] = __builtin_bit_cast(pt_h2, __builtin_amdgcn_perm(0u, nx, 0x0c030c02u));
+        hny[0] = __builtin_bit_cast(pt_h2, __builtin_amdgcn_perm(0u, ny, 0x0c010c00u)); hny[1] = __builtin_bit_cast(pt_h2, __builtin_amdgcn_perm(0u, ny, 0x0c030c02u));
+        hnz[0] = __builtin_bit_cast(pt_h2, __builtin_amdgcn_perm(0u, nz, 0x0c010c00u)); hnz[1] = __builtin_bit_cast(pt_h2, __builtin_amdgcn_perm(0u, nz, 0x0c030c02u));
+        hfx[0] = __builtin_bit_cast(pt_h2, __builtin_amdgcn_perm(0u, fx, 0x0c010c00u)); hfx[1] = __builtin_bit_cast(pt_h2, __builtin_amdgcn_perm(0u, fx, 0x0c030c02u));
+        hfy[0] = __builtin_bit_cast(pt_h2, __builtin_amdgcn_perm(0u, fy, 0x0c010c00u)); hfy[1] = __builtin_bit_cast(pt_h2, __builtin_amdgcn_perm(0u, fy, 0x0c030c02u));
+        hfz[0] = __builtin_bit_cast(pt_h2, __builtin_amdgcn_perm(0u, fz, 0x0c010c00u)); hfz[1] = __builtin_bit_cast(pt_h2, __builtin_amdgcn_perm(0u, fz, 0x0c030c02u));
+      }
+#endif
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        float tnx = __builtin_fmaf((float)((nx >> (8 * j)) & 0xffu), ax, bx);
-        float tny = __builtin_fmaf((float)((ny >> (8 * j)) & 0xffu), ay, by);
-        float tnz = __builtin_fmaf((float)((nz >> (8 * j)) & 0xffu), az, bz);
-        float tfx = __builtin_fmaf((float)((fx >> (8 * j)) & 0xffu), ax, bx);
-        float tfy = __builtin_fmaf((float)((fy >> (8 * j)) & 0xffu), ay, by);
-        float tfz = __builtin_fmaf((float)((fz >> (8 * j)) & 0xffu), az, bz);
+        float tnx, tny, tnz, tfx, tfy, tfz;
+#if PT_MIX_FMA
+        if (!SAFE) {
+          tnx = __builtin_fmaf((float)hnx[j >> 1][j & 1], ax, bx);
+          tny = __builtin_fmaf((float)hny[j >> 1][j & 1], ay, by);
+          tnz = __builtin_fmaf((float)hnz[j >> 1][j & 1], az, bz);
+          tfx = __builtin_fmaf((float)hfx[j >> 1][j & 1], ax, bx);
+          tfy = __builtin_fmaf((float)hfy[j >> 1][j & 1], ay, by);
+          tfz = __builtin_fmaf((float)hfz[j >> 1][j & 1], az, bz);
+        } else
+#endif
+        {
+          tnx = __builtin_fmaf((float)((nx >> (8 * j)) & 0xffu), ax, bx);
+          tny = __builtin_fmaf((float)((ny >> (8 * j)) & 0xffu), ay, by);
+          tnz = __builtin_fmaf((float)((nz >> (8 * j)) & 0xffu), az, bz);
+          tfx = __builtin_fmaf((float)((fx >> (8 * j)) & 0xffu), ax, bx);
+          tfy = __builtin_fmaf((float)((fy >> (8 * j)) & 0xffu), ay, by);
+          tfz = __builtin_fmaf((float)((fz >> (8 * j)) & 0xffu), az, bz);
+        }
         if (SAFE) { tnx *= idx; tny *= idy; tnz *= idz; tfx *= idx; tfy *= idy; tfz *= idz; }
         const float tn = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, ray.tmin));
         const float tf = fminf(fminf(tfx, tfy), fminf(tfz, best.t));
@@ -269,7 +302,11 @@ struct Traverser {
     if (wave_risky && risky) {
       child_tests<true>(n1, n2, n3, n4, sx, sy, sz, px, py, pz, negx, negy, negz, oct4, hitmask);
     } else {
+#if PT_MIX_FMA
+      child_tests<false>(n1, n2, n3, n4, sx * idx * 16777216.0f, sy * idy * 16777216.0f, sz * idz * 16777216.0f, px * idx, py * idy, pz * idz, negx, negy, negz, oct4, hitmask);
+#else
       child_tests<false>(n1, n2, n3, n4, sx * idx, sy * idy, sz * idz, px * idx, py * idy, pz * idz, negx, negy, negz, oct4, hitmask);
+#endif
     }
     ng.x = n1.x;
     ng.y = (hitmask & 0xFF000000u) | (e >> 24);
