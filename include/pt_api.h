@@ -132,7 +132,13 @@ enum {
   PT_SCENE_DEFAULT = 0,
   /* The reference never transforms normals by the instance matrix (PathTracing.hlsl:24-27).
      Set this to rotate them by the upper 3x3 of myTransform instead. */
-  PT_SCENE_TRANSFORM_NORMALS = 1
+  PT_SCENE_TRANSFORM_NORMALS = 1,
+  /* Leaf records of the acceleration structure: by default the builder pairs edge-sharing triangles into 64-byte records
+     once the scene is too large for the 256 MB Infinity Cache (a third less memory, +9.5 % on 10.5 M triangles) and keeps
+     48-byte single-triangle records below that (pairs cost 4 % there). These flags force one or the other; hit records
+     are identical either way. */
+  PT_SCENE_PAIR_TRIANGLES = 2,
+  PT_SCENE_NO_PAIRS = 4
 };
 
 /* closest-hit record returned by the trace entry points */
@@ -310,11 +316,12 @@ int pt_debug_eval(pt_ctx* ctx, int fn, const PtRtConsts* consts, const float* in
 /* Copy out the ray queue that the LAST wavefront batch built for `bounce` (valid until the next render call; the
    queue of bounce b is overwritten by bounce b+2 of the same batch). host_rays may be NULL to query the count. */
 int pt_debug_read_queue(pt_ctx* ctx, uint32_t bounce, PtRay* host_rays, uint64_t capacity, uint64_t* count_out);
-/* Copy the acceleration structure as it lives on the device back to the host: 80-byte nodes and 48-byte triangle
-   records (layout: pathtracer_amd/csrc/bvh8.h), plus the scene magnitude the box test's overflow guard uses. With both
-   arrays NULL only the counts are returned. Lets tests walk the very hierarchy the kernel walks (tests/walker/). */
+/* Copy the acceleration structure as it lives on the device back to the host: 80-byte nodes and leaf records of
+   *record_bytes each (48 = one triangle, 64 = one triangle or an edge-sharing pair; layout: pathtracer_amd/csrc/bvh8.h),
+   plus the scene magnitude the box test's overflow guard uses. With both arrays NULL only the counts are returned
+   (capacities are in records). Lets tests walk the very hierarchy the kernel walks (tests/walker/). */
 int pt_debug_read_bvh(pt_ctx* ctx, void* nodes, uint64_t node_capacity, void* tris, uint64_t tri_capacity,
-                      uint64_t* num_nodes, uint64_t* num_tris, float* scene_mag);
+                      uint64_t* num_nodes, uint64_t* num_tris, float* scene_mag, uint32_t* record_bytes);
 int pt_stats_get(pt_ctx* ctx, PtStats* out);   /* synchronises the stream first */
 int pt_stats_reset(pt_ctx* ctx);
 

@@ -27,6 +27,8 @@ PT_ERR_UNSUPPORTED = 9
 PT_MISS = 0xFFFFFFFF
 PT_SCENE_DEFAULT = 0
 PT_SCENE_TRANSFORM_NORMALS = 1
+PT_SCENE_PAIR_TRIANGLES = 2
+PT_SCENE_NO_PAIRS = 4
 
 PT_OPT_COUNT_TRAVERSAL = 1
 PT_OPT_TIME_KERNELS = 2
@@ -166,7 +168,8 @@ SYMBOLS = {
     "pt_occluded": (C.c_int, [_P, _P, C.c_uint64, _P]),
     "pt_debug_eval": (C.c_int, [_P, C.c_int, C.POINTER(PtRtConsts), _P, C.c_uint64, _P]),
     "pt_debug_read_queue": (C.c_int, [_P, C.c_uint32, _P, C.c_uint64, C.POINTER(C.c_uint64)]),
-    "pt_debug_read_bvh": (C.c_int, [_P, _P, C.c_uint64, _P, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_float)]),
+    "pt_debug_read_bvh": (C.c_int, [_P, _P, C.c_uint64, _P, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_float),
+                                   C.POINTER(C.c_uint32)]),
     "pt_stats_get": (C.c_int, [_P, C.POINTER(PtStats)]),
     "pt_stats_reset": (C.c_int, [_P]),
 }

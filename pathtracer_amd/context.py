@@ -202,12 +202,13 @@ class Context:
         return out
 
     def debug_read_bvh(self):
-        """(nodes uint8[n,80], tris uint8[m,48], scene_mag): the BVH8 as it lives on the device (csrc/bvh8.h)."""
-        nn, nt, mag = C.c_uint64(), C.c_uint64(), C.c_float()
-        self._ck(self.lib.pt_debug_read_bvh(self.h, None, 0, None, 0, C.byref(nn), C.byref(nt), C.byref(mag)))
+        """(nodes uint8[n,80], records uint8[m,48 or 64], scene_mag): the BVH8 as it lives on the device (csrc/bvh8.h);
+        48-byte records hold one triangle, 64-byte records one triangle or an edge-sharing pair."""
+        nn, nt, mag, rb = C.c_uint64(), C.c_uint64(), C.c_float(), C.c_uint32()
+        self._ck(self.lib.pt_debug_read_bvh(self.h, None, 0, None, 0, C.byref(nn), C.byref(nt), C.byref(mag), C.byref(rb)))
         nodes = np.empty((max(1, nn.value), 80), dtype=np.uint8)
-        tris = np.empty((max(1, nt.value), 48), dtype=np.uint8)
-        self._ck(self.lib.pt_debug_read_bvh(self.h, api.ptr(nodes), nn.value, api.ptr(tris), nt.value, None, None, None))
+        tris = np.empty((max(1, nt.value), rb.value), dtype=np.uint8)
+        self._ck(self.lib.pt_debug_read_bvh(self.h, api.ptr(nodes), nn.value, api.ptr(tris), nt.value, None, None, None, None))
         return nodes[:nn.value], tris[:nt.value], mag.value
 
     # ---- misc ----

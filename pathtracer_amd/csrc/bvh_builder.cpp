@@ -206,9 +206,73 @@ static inline int dec_kr(uint8_t d) { return (d >> 5) & 7; }
 
 struct ChildRef { uint32_t n2; bool leaf; };
 
+// ---- pairing of edge-sharing triangles ----
+// Greedy matching in triangle-id order over an open-addressing table keyed by the (order-independent) hash of an
+// edge's two vertex positions. A table hit is only a candidate: the pair is accepted after comparing positions bit
+// for bit. partner[i] = the triangle paired with i (the lower id of a pair owns the record) or 0xFFFFFFFF.
+static inline uint64_t mix64(uint64_t x) {
+  x ^= x >> 33; x *= 0xff51afd7ed558ccdull; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ull; x ^= x >> 33;
+  return x;
+}
+static inline uint64_t vertex_key(const float* v) {
+  uint32_t b[3];
+  memcpy(b, v, 12);
+  return mix64(((uint64_t)b[0] << 32 | b[1]) ^ mix64((uint64_t)b[2] + 0x9e3779b97f4a7c15ull));
+}
+static inline bool same_vertex(const float* a, const float* b) { return memcmp(a, b, 12) == 0; }
+
+static int shared_vertices(const float* ta, const float* tb) {
+  int n = 0;
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j)
+      if (same_vertex(ta + 3 * i, tb + 3 * j)) { ++n; break; }
+  return n;
+}
+
+static void pair_triangles(const float* verts, const std::vector<uint32_t>& active, uint32_t n, std::vector<uint32_t>& partner) {
+  partner.assign(n, 0xFFFFFFFFu);
+  if (active.size() < 2) return;
+  size_t cap = 64;
+  while (cap < active.size() * 6) cap <<= 1;
+  struct Slot { uint32_t tag, tri; };
+  std::vector<Slot> table(cap, Slot{0u, 0xFFFFFFFFu});
+  const size_t mask = cap - 1;
+  for (uint32_t i : active) {
+    const float* t = verts + (size_t)i * 9;
+    uint64_t vk[3] = {vertex_key(t), vertex_key(t + 3), vertex_key(t + 6)};
+    uint64_t ek[3];
+    for (int e = 0; e < 3; ++e) {   // order-independent edge key
+      const uint64_t a = vk[e], b = vk[(e + 1) % 3];
+      ek[e] = mix64((a ^ b) + (a + b) * 0x9e3779b97f4a7c15ull);
+    }
+    bool paired = false;
+    for (int e = 0; e < 3 && !paired; ++e) {
+      const uint32_t tag = (uint32_t)(ek[e] >> 32) | 1u;
+      for (size_t s = ek[e] & mask;; s = (s + 1) & mask) {
+        const Slot sl = table[s];
+        if (sl.tri == 0xFFFFFFFFu && sl.tag == 0u) break;            // empty: this edge was never entered
+        if (sl.tag == tag && sl.tri != 0xFFFFFFFFu && sl.tri != i && partner[sl.tri] == 0xFFFFFFFFu &&
+            shared_vertices(verts + (size_t)sl.tri * 9, t) >= 2) {
+          partner[sl.tri] = i;
+          partner[i] = sl.tri;
+          paired = true;
+          break;
+        }
+      }
+    }
+    if (paired) continue;
+    for (int e = 0; e < 3; ++e) {   // offer this triangle's edges to later ones
+      const uint32_t tag = (uint32_t)(ek[e] >> 32) | 1u;
+      for (size_t s = ek[e] & mask;; s = (s + 1) & mask) {
+        if (table[s].tag == 0u) { table[s] = Slot{tag, i}; break; }
+      }
+    }
+  }
+}
+
 }  // namespace
 
-void build_bvh8(const float* verts, uint32_t n, Bvh8& out, int num_threads) {
+void build_bvh8(const float* verts, uint32_t n, Bvh8& out, int num_threads, int pair_mode) {
   auto t0 = std::chrono::steady_clock::now();
   if (num_threads <= 0) {
     num_threads = (int)std::thread::hardware_concurrency();
@@ -217,7 +281,12 @@ void build_bvh8(const float* verts, uint32_t n, Bvh8& out, int num_threads) {
   }
   out.nodes.clear();
   out.tris.clear();
+  out.prims.clear();
+  out.num_pairs = 0;
   out.max_depth = 0;
+  if (const char* e = getenv("PT_BVH_PAIRS")) pair_mode = atoi(e);   // tuning runs
+  // auto: an unpaired hierarchy costs ~56 bytes per triangle (48-byte record + its share of the nodes)
+  out.paired = pair_mode > 0 || (pair_mode < 0 && (double)n * 56.0 > 224.0 * 1024.0 * 1024.0);
 
   // ---- active triangles, scene bounds and the conservative pad (see DESIGN.md "box conservativeness") ----
   // A triangle with a NaN or infinite vertex can never be hit (every comparison of the intersection test fails), so it
@@ -249,17 +318,42 @@ void build_bvh8(const float* verts, uint32_t n, Bvh8& out, int num_threads) {
     return;
   }
 
-  std::vector<Prim> prims(n);
+  // ---- primitives: edge-sharing triangles in pairs, the rest alone ----
+  std::vector<uint32_t> partner;
+  if (out.paired) pair_triangles(verts, order, n, partner);
+  else partner.assign(n, 0xFFFFFFFFu);
+  struct PrimRef { uint32_t a, b; };
+  std::vector<PrimRef> refs;
+  refs.reserve(order.size());
   for (uint32_t i : order) {
-    const float* v = verts + (size_t)i * 9;
-    for (int a = 0; a < 3; ++a) {
-      float lo = std::min(v[a], std::min(v[3 + a], v[6 + a]));
-      float hi = std::max(v[a], std::max(v[3 + a], v[6 + a]));
-      prims[i].lo[a] = lo - pad;
-      prims[i].hi[a] = hi + pad;
-      prims[i].c[a] = 0.5f * lo + 0.5f * hi;   // not 0.5*(lo+hi): the sum can overflow for |coordinates| near FLT_MAX
-    }
+    if (partner[i] == 0xFFFFFFFFu) refs.push_back({i, 0xFFFFFFFFu});
+    else if (partner[i] > i) refs.push_back({i, partner[i]});
   }
+  const uint32_t np = (uint32_t)refs.size();
+  std::vector<Prim> prims(np);
+  std::vector<float> weight(np);      // SAH weight of a record: one triangle test, or two that share their set-up
+  for (uint32_t k = 0; k < np; ++k) {
+    Prim& p = prims[k];
+    for (int a = 0; a < 3; ++a) { p.lo[a] = FLT_MAX; p.hi[a] = -FLT_MAX; }
+    for (int h = 0; h < 2; ++h) {
+      const uint32_t t = h ? refs[k].b : refs[k].a;
+      if (t == 0xFFFFFFFFu) continue;
+      const float* v = verts + (size_t)t * 9;
+      for (int a = 0; a < 3; ++a) {
+        p.lo[a] = std::min(p.lo[a], std::min(v[a], std::min(v[3 + a], v[6 + a])));
+        p.hi[a] = std::max(p.hi[a], std::max(v[a], std::max(v[3 + a], v[6 + a])));
+      }
+    }
+    for (int a = 0; a < 3; ++a) {
+      p.c[a] = 0.5f * p.lo[a] + 0.5f * p.hi[a];   // not 0.5*(lo+hi): the sum can overflow for |coordinates| near FLT_MAX
+      p.lo[a] -= pad;
+      p.hi[a] += pad;
+    }
+    weight[k] = refs[k].b == 0xFFFFFFFFu ? 1.0f : 1.6f;
+    if (refs[k].b != 0xFFFFFFFFu) out.num_pairs++;
+  }
+  order.resize(np);
+  for (uint32_t k = 0; k < np; ++k) order[k] = k;
   std::vector<Node2> n2;
   Builder2(prims, order, n2, num_threads).run();
   const uint32_t nn = (uint32_t)n2.size();
@@ -272,15 +366,18 @@ void build_bvh8(const float* verts, uint32_t n, Bvh8& out, int num_threads) {
   std::vector<double> cost((size_t)nn * 7);
   std::vector<uint8_t> dec((size_t)nn * 7);
   std::vector<uint8_t> isplit(nn, 0);
+  std::vector<float> wsum(nn, 0.0f);   // SAH weight of the records below a node (children are allocated after their parent)
   for (uint32_t idx = nn; idx-- > 0;) {
     const Node2& nd = n2[idx];
     const double A = half_area(nd.lo, nd.hi);
     double* c = &cost[(size_t)idx * 7];
     uint8_t* d = &dec[(size_t)idx * 7];
     if (nd.left == 0) {
-      for (int i = 0; i < 7; ++i) { c[i] = A * Cprim * (double)nd.count; d[i] = mk_dec(D_LEAF, 0, 0); }
+      for (uint32_t i = 0; i < nd.count; ++i) wsum[idx] += weight[order[nd.first + i]];
+      for (int i = 0; i < 7; ++i) { c[i] = A * Cprim * (double)wsum[idx]; d[i] = mk_dec(D_LEAF, 0, 0); }
       continue;
     }
+    wsum[idx] = wsum[nd.left] + wsum[nd.left + 1];
     const double* cl = &cost[(size_t)nd.left * 7];
     const double* cr = &cost[(size_t)(nd.left + 1) * 7];
     double cdist[9]; int ksplit[9];
@@ -293,7 +390,7 @@ void build_bvh8(const float* verts, uint32_t n, Bvh8& out, int num_threads) {
       }
       cdist[j] = best; ksplit[j] = bk;
     }
-    const double cleaf = nd.count <= PT_BVH8_MAX_LEAF_TRIS ? A * Cprim * (double)nd.count : DBL_MAX;
+    const double cleaf = nd.count <= PT_BVH8_MAX_LEAF_TRIS ? A * Cprim * (double)wsum[idx] : DBL_MAX;
     const double cint = cdist[8] + A * Cnode;
     isplit[idx] = (uint8_t)ksplit[8];
     if (cleaf <= cint) { c[0] = cleaf; d[0] = mk_dec(D_LEAF, 0, 0); }
@@ -309,7 +406,7 @@ void build_bvh8(const float* verts, uint32_t n, Bvh8& out, int num_threads) {
   struct Work { uint32_t n2; uint32_t out; uint32_t depth; };
   std::deque<Work> queue;
   out.nodes.reserve(nn / 4 + 16);
-  out.tris.reserve(n);
+  if (out.paired) out.prims.reserve(np); else out.tris.reserve(np);
   out.nodes.emplace_back();
   queue.push_back({0, 0, 1});
   std::vector<ChildRef> kids;
@@ -410,7 +507,7 @@ void build_bvh8(const float* verts, uint32_t n, Bvh8& out, int num_threads) {
 
     // children: internal ones contiguous in slot order, leaf triangles appended in slot order
     node.child_base = (uint32_t)out.nodes.size();
-    node.tri_base = (uint32_t)out.tris.size();
+    node.tri_base = (uint32_t)out.num_records();
     uint32_t ninternal = 0, tri_off = 0;
     for (int s = 0; s < 8; ++s) {
       if (slot_child[s] < 0) { node.meta[s] = 0; continue; }
@@ -426,12 +523,35 @@ void build_bvh8(const float* verts, uint32_t n, Bvh8& out, int num_threads) {
         const uint32_t unary = cnt == 1 ? 1u : (cnt == 2 ? 3u : 7u);
         node.meta[s] = (uint8_t)((unary << 5) | tri_off);
         for (uint32_t i = 0; i < cnt; ++i) {
-          uint32_t prim = order[ch.first + i];
-          const float* v = verts + (size_t)prim * 9;
-          PtTriRecord tr;
+          const PrimRef& pr = refs[order[ch.first + i]];
+          const float* v = verts + (size_t)pr.a * 9;
+          if (!out.paired) {
+            PtTriRecord t3;
+            memcpy(t3.v0, v, 12); memcpy(t3.v1, v + 3, 12); memcpy(t3.v2, v + 6, 12);
+            t3.prim = pr.a; t3.pad0 = 0; t3.pad1 = 0;
+            out.tris.push_back(t3);
+            continue;
+          }
+          PtPrimRecord tr;
           memcpy(tr.v0, v, 12); memcpy(tr.v1, v + 3, 12); memcpy(tr.v2, v + 6, 12);
-          tr.prim = prim; tr.pad0 = 0; tr.pad1 = 0;
-          out.tris.push_back(tr);
+          memcpy(tr.v3, v + 6, 12);
+          tr.prim0 = pr.a; tr.prim1 = 0xFFFFFFFFu; tr.code = 0u; tr.pad = 0u;
+          if (pr.b != 0xFFFFFFFFu) {
+            // triangle b in ITS vertex order, each vertex as an index into {v0, v1, v2, v3}; v3 = its one vertex
+            // that triangle a does not have (pairs share at least two vertices, so there is at most one such)
+            const float* w = verts + (size_t)pr.b * 9;
+            uint32_t code = 0u;
+            for (int k = 0; k < 3; ++k) {
+              uint32_t idx = 3u;
+              for (int m = 0; m < 3; ++m)
+                if (same_vertex(w + 3 * k, v + 3 * m)) { idx = (uint32_t)m; break; }
+              if (idx == 3u) memcpy(tr.v3, w + 3 * k, 12);
+              code |= idx << (2 * k);
+            }
+            tr.prim1 = pr.b;
+            tr.code = code;
+          }
+          out.prims.push_back(tr);
         }
         tri_off += cnt;
       }

@@ -3,13 +3,21 @@
 #pragma once
 #include <cstdint>
 #include <vector>
+#include <cstddef>
+
 #include "bvh8.h"
 
 namespace pt {
 
 struct Bvh8 {
   std::vector<PtBvh8Node> nodes;   // node 0 is the root
-  std::vector<PtTriRecord> tris;   // leaf order
+  bool paired = false;             // which record format the leaves reference
+  std::vector<PtTriRecord> tris;   // !paired: 48-byte triangle records, leaf order
+  std::vector<PtPrimRecord> prims; // paired: 64-byte records (one triangle or an edge-sharing pair each), leaf order
+  uint32_t num_pairs = 0;          // records that hold two triangles
+  size_t num_records() const { return paired ? prims.size() : tris.size(); }
+  size_t record_bytes() const { return paired ? sizeof(PtPrimRecord) : sizeof(PtTriRecord); }
+  const void* records() const { return paired ? (const void*)prims.data() : (const void*)tris.data(); }
   uint32_t max_depth = 0;          // number of node levels on the longest root-to-leaf path
   float lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
   double build_ms = 0.0;
@@ -17,8 +25,11 @@ struct Bvh8 {
 };
 
 // verts: 9 floats per triangle (v0,v1,v2 world space); triangle i gets global id i.
-// Binned-SAH binary BVH (single-triangle leaves) -> SAH-optimal collapse to 8-wide nodes with <=3 triangles per
+// Edge-sharing triangles are paired into primitives first (greedy, by exact vertex positions). Binned-SAH binary BVH
+// over the primitives (single-primitive leaves) -> SAH-optimal collapse to 8-wide nodes with <=3 records per
 // leaf -> octant-ordered child slots -> 8-bit quantisation (conservative, padded by a scene-relative epsilon).
-void build_bvh8(const float* verts, uint32_t num_tris, Bvh8& out, int num_threads = 0);
+// pair_mode: 0 = triangle records, 1 = pair edge-sharing triangles, -1 = decide by size (pairs once the unpaired hierarchy
+// would exceed the Infinity Cache: measured +9.5 % on 10.5 M triangles, -4 % on 262 k).
+void build_bvh8(const float* verts, uint32_t num_tris, Bvh8& out, int num_threads = 0, int pair_mode = -1);
 
 }  // namespace pt

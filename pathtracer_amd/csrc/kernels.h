@@ -9,7 +9,8 @@ namespace pt {
 // device-resident scene (all pointers are device memory)
 struct DeviceScene {
   const uint4* nodes = nullptr;        // 5 x uint4 per 80-byte BVH8 node
-  const uint4* tris = nullptr;         // 3 x uint4 per 48-byte triangle record (leaf order)
+  const uint4* tris = nullptr;         // leaf records: 48-byte triangles, or (paired) 64-byte records of one triangle or an edge-sharing pair
+  bool paired = false;                 // record format of `tris` (csrc/bvh8.h)
   const uint4* prim_data = nullptr;    // per global triangle id: i0,i1,i2 (global vertex ids), instance id
   const float4* vertex_normal = nullptr;
   const float4* prim_shade = nullptr;  // 4 x float4 per global triangle id: {n0, instance id bits}, {n1, -}, {n2, -}, {emission, rgba8 bits}:
@@ -99,6 +100,6 @@ void launch_add(float4* dst, const float4* src, uint64_t n, hipStream_t s);   //
 void launch_set_count(uint32_t* counter, uint32_t value, hipStream_t s);
 void launch_debug_eval(int fn, const PtRtConsts& c, const uint2* lut, const float4* skyview, const float* in, uint64_t n, float* out, hipStream_t s);
 size_t extend_lds_bytes(uint32_t lds_entries_total, uint32_t top_nodes);
-int extend_occupancy_blocks(uint32_t lds_entries_total, uint32_t top_nodes, bool defer);
+int extend_occupancy_blocks(uint32_t lds_entries_total, uint32_t top_nodes, bool defer, bool paired);
 
 }  // namespace pt

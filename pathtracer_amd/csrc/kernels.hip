@@ -125,7 +125,10 @@ __global__ void __launch_bounds__(256) k_generate(PtRtConsts c, float4* __restri
 // stack while fewer than postpone_pct % of the busy lanes have any. Either way the wave spends its instructions on box
 // tests or on triangle tests with most lanes active.
 
-template <bool COUNT, bool DEFER>
+template <bool COUNT, bool DEFER, bool PAIRS>
+#ifdef PT_EXP_EXTEND_W6
+__attribute__((amdgpu_waves_per_eu(6)))
+#endif
 __global__ void __launch_bounds__(256) k_extend(const uint4* __restrict__ nodes, const uint4* __restrict__ tris,
                                                 const float4* __restrict__ ray_o, const float4* __restrict__ ray_d,
                                                 float4* __restrict__ hits, const uint32_t* __restrict__ count_ptr,
@@ -241,8 +244,8 @@ __global__ void __launch_bounds__(256) k_extend(const uint4* __restrict__ nodes,
         }
         if (COUNT) ++n_tri_steps;
         if (has) {
-          tr.tri_step(tris);
-          if (COUNT) ++n_tris;
+          const uint32_t nt = tr.template tri_step<PAIRS>(tris);
+          if (COUNT) n_tris += nt;
         }
       }
       if (any_hit && busy && tr.best.prim != 0xFFFFFFFFu) { tr.ng.y = 0u; tr.tg.y = 0u; tr.sp = 0; }
@@ -277,8 +280,8 @@ __global__ void __launch_bounds__(256) k_extend(const uint4* __restrict__ nodes,
             if (must == 0ull && (uint32_t)__popcll(m) * 100u < n_busy * continue_pct) break;   // tail: leave the rest parked
             if (COUNT) ++n_tri_steps;
             if (has) {
-              tr.tri_step(tris);
-              if (COUNT) ++n_tris;
+              const uint32_t nt = tr.template tri_step<PAIRS>(tris);
+              if (COUNT) n_tris += nt;
             }
           }
         }
@@ -728,10 +731,14 @@ size_t extend_lds_bytes(uint32_t lds_entries_total, uint32_t top_nodes) {
   return (size_t)lds_entries_total * 64u * sizeof(uint2) * 4u + (size_t)top_nodes * PT_NODE_STRIDE_U4 * 16u;
 }
 
-int extend_occupancy_blocks(uint32_t lds_entries_total, uint32_t top_nodes, bool defer) {
+int extend_occupancy_blocks(uint32_t lds_entries_total, uint32_t top_nodes, bool defer, bool paired) {
   int nb = 0;
-  const hipError_t e = defer ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_extend<false, true>, 256, extend_lds_bytes(lds_entries_total, top_nodes))
-                             : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_extend<false, false>, 256, extend_lds_bytes(lds_entries_total, top_nodes));
+  const size_t lds = extend_lds_bytes(lds_entries_total, top_nodes);
+  // per instantiation: the pair test holds one more vertex in registers (5 waves per SIMD instead of 6)
+  const hipError_t e = paired ? (defer ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_extend<false, true, true>, 256, lds)
+                                       : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_extend<false, false, true>, 256, lds))
+                              : (defer ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_extend<false, true, false>, 256, lds)
+                                       : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_extend<false, false, false>, 256, lds));
   if (e != hipSuccess || nb < 1) nb = 1;
   return nb;
 }
@@ -748,19 +755,21 @@ void launch_extend(const DeviceScene& sc, const float4* ray_o, const float4* ray
   const size_t lds = extend_lds_bytes(lds_entries + dq, top_nodes);
   if (lds > 64 * 1024) {   // deep BVHs: opt in to more than the default dynamic-LDS limit. The attribute belongs to the CURRENT
                            // device (one process may drive several, pt_reduce), so it is set on every such launch: no cached flag.
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_extend<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_extend<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_extend<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_extend<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+#define PT_EXTEND_ATTR(C, D, P) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_extend<C, D, P>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
+    PT_EXTEND_ATTR(false, false, false); PT_EXTEND_ATTR(true, false, false); PT_EXTEND_ATTR(false, true, false); PT_EXTEND_ATTR(true, true, false);
+    PT_EXTEND_ATTR(false, false, true); PT_EXTEND_ATTR(true, false, true); PT_EXTEND_ATTR(false, true, true); PT_EXTEND_ATTR(true, true, true);
+#undef PT_EXTEND_ATTR
   }
-#define PT_LAUNCH_EXTEND(C, D)                                                                                              \
-  hipLaunchKernelGGL((k_extend<C, D>), dim3(cfg.extend_blocks), dim3(256), lds, s, sc.nodes, sc.tris, ray_o, ray_d, hits, count, \
+#define PT_LAUNCH_EXTEND(C, D, P)                                                                                           \
+  hipLaunchKernelGGL((k_extend<C, D, P>), dim3(cfg.extend_blocks), dim3(256), lds, s, sc.nodes, sc.tris, ray_o, ray_d, hits, count, \
                      work_cursor, stats, lds_entries, spill_entries, sc.spill, stride, cfg.fetch_min, cfg.postpone_pct, dq, any_hit ? 1u : 0u, sc.scene_mag, top_nodes, cfg.continue_pct)
+#define PT_LAUNCH_EXTEND2(C, D) do { if (sc.paired) PT_LAUNCH_EXTEND(C, D, true); else PT_LAUNCH_EXTEND(C, D, false); } while (0)
   if (dq > 0) {
-    if (count_traversal) PT_LAUNCH_EXTEND(true, true); else PT_LAUNCH_EXTEND(false, true);
+    if (count_traversal) PT_LAUNCH_EXTEND2(true, true); else PT_LAUNCH_EXTEND2(false, true);
   } else {
-    if (count_traversal) PT_LAUNCH_EXTEND(true, false); else PT_LAUNCH_EXTEND(false, false);
+    if (count_traversal) PT_LAUNCH_EXTEND2(true, false); else PT_LAUNCH_EXTEND2(false, false);
   }
+#undef PT_LAUNCH_EXTEND2
 #undef PT_LAUNCH_EXTEND
 }
 

@@ -37,6 +37,7 @@ struct pt_ctx {
   std::vector<void*> scene_allocs;
   std::vector<uint32_t> instance_material;   // host copy, for pt_scene_set_material_ext
   uint32_t num_materials = 0;
+  uint64_t num_records = 0;                  // leaf records of the BVH (48-byte triangles or 64-byte pairs, ds.paired)
   float4* instance_ext = nullptr;
   PtSceneInfo info{};
 
@@ -217,7 +218,7 @@ int extend_grid(pt_ctx* ctx) {
   int per_cu = ctx->cfg.extend_blocks_per_cu;
   if (per_cu <= 0) {
     const uint32_t lds_entries = std::min<uint32_t>(std::min(ctx->ds.stack_entries, ctx->cfg.lds_stack_entries) + ctx->cfg.defer_entries, PT_EXTEND_MAX_LDS_ENTRIES);
-    per_cu = std::max(1, std::min(8, extend_occupancy_blocks(lds_entries, std::min<uint32_t>(ctx->cfg.top_nodes, ctx->ds.num_nodes), ctx->cfg.defer_entries > 0)));
+    per_cu = std::max(1, std::min(8, extend_occupancy_blocks(lds_entries, std::min<uint32_t>(ctx->cfg.top_nodes, ctx->ds.num_nodes), ctx->cfg.defer_entries > 0, ctx->ds.paired)));
   }
   return ctx->cfg.num_cus * per_cu;
 }
@@ -422,11 +423,11 @@ int pt_scene_create(pt_ctx* ctx, const PtMeshDesc* meshes, uint32_t num_meshes, 
   int rc = flatten_scene(meshes, num_meshes, instances, num_instances, materials, num_materials, flags, fs, err);
   if (rc != PT_OK) return ctx->fail(rc, err);
   Bvh8 bvh;
-  build_bvh8(fs.tri_verts.data(), fs.num_triangles(), bvh);
+  build_bvh8(fs.tri_verts.data(), fs.num_triangles(), bvh, 0, (flags & PT_SCENE_PAIR_TRIANGLES) ? 1 : ((flags & PT_SCENE_NO_PAIRS) ? 0 : -1));
 
   // the traversal kernel addresses nodes and triangle records with 32-bit byte offsets
-  if (bvh.nodes.size() * (size_t)(PT_NODE_STRIDE_U4 * 16) >= (1ull << 32) || bvh.tris.size() * sizeof(PtTriRecord) >= (1ull << 32))
-    return ctx->fail(PT_ERR_UNSUPPORTED, "scene too large: more than 4 GB of BVH nodes or of triangle records (89 M triangles)");
+  if (bvh.nodes.size() * (size_t)(PT_NODE_STRIDE_U4 * 16) >= (1ull << 32) || bvh.num_records() * bvh.record_bytes() >= (1ull << 32))
+    return ctx->fail(PT_ERR_UNSUPPORTED, "scene too large: more than 4 GB of BVH nodes or of leaf records");
   PT_HIP(hipStreamSynchronize(ctx->stream));
   free_list(ctx->scene_allocs);
   if (ctx->instance_ext) { (void)hipFree(ctx->instance_ext); ctx->instance_ext = nullptr; }
@@ -438,7 +439,7 @@ int pt_scene_create(pt_ctx* ctx, const PtMeshDesc* meshes, uint32_t num_meshes, 
   float2* d_uv;
   uint32_t* d_im;
   if ((rc = dev_alloc(ctx, &d_nodes, bvh.nodes.size() * PT_NODE_STRIDE_U4, &ctx->scene_allocs))) return rc;
-  if ((rc = dev_alloc(ctx, &d_tris, bvh.tris.size() * 3, &ctx->scene_allocs))) return rc;
+  if ((rc = dev_alloc(ctx, &d_tris, bvh.num_records() * bvh.record_bytes() / 16, &ctx->scene_allocs))) return rc;
   if ((rc = dev_alloc(ctx, &d_prim, (size_t)fs.num_triangles(), &ctx->scene_allocs))) return rc;
   if ((rc = dev_alloc(ctx, &d_vn, (size_t)fs.num_vertices(), &ctx->scene_allocs))) return rc;
   if ((rc = dev_alloc(ctx, &d_uv, (size_t)fs.num_vertices(), &ctx->scene_allocs))) return rc;
@@ -462,7 +463,7 @@ int pt_scene_create(pt_ctx* ctx, const PtMeshDesc* meshes, uint32_t num_meshes, 
     PT_HIP(up(d_nodes, padded.data(), padded.size()));
   }
 #endif
-  PT_HIP(up(d_tris, bvh.tris.data(), bvh.tris.size() * sizeof(PtTriRecord)));
+  PT_HIP(up(d_tris, bvh.records(), bvh.num_records() * bvh.record_bytes()));
   PT_HIP(up(d_prim, fs.prim_data.data(), fs.prim_data.size() * 4));
   PT_HIP(up(d_vn, fs.vertex_normal.data(), fs.vertex_normal.size() * 4));
   PT_HIP(up(d_uv, fs.vertex_uv.data(), fs.vertex_uv.size() * 4));
@@ -489,6 +490,8 @@ int pt_scene_create(pt_ctx* ctx, const PtMeshDesc* meshes, uint32_t num_meshes, 
 
   ctx->ds.nodes = d_nodes;
   ctx->ds.tris = d_tris;
+  ctx->ds.paired = bvh.paired;
+  ctx->num_records = bvh.num_records();
   ctx->ds.prim_data = d_prim;
   ctx->ds.vertex_normal = d_vn;
   ctx->ds.vertex_uv = d_uv;
@@ -520,7 +523,7 @@ int pt_scene_create(pt_ctx* ctx, const PtMeshDesc* meshes, uint32_t num_meshes, 
   in.num_materials = num_materials;
   in.num_bvh_nodes = (uint32_t)bvh.nodes.size();
   in.bvh_max_depth = bvh.max_depth;
-  in.bvh_bytes = bvh.nodes.size() * sizeof(PtBvh8Node) + bvh.tris.size() * sizeof(PtTriRecord);
+  in.bvh_bytes = bvh.nodes.size() * sizeof(PtBvh8Node) + bvh.num_records() * bvh.record_bytes();
   for (int a = 0; a < 3; ++a) { in.bounds_min[a] = bvh.lo[a]; in.bounds_max[a] = bvh.hi[a]; }
   in.build_ms = bvh.build_ms;
   ctx->has_scene = true;
@@ -971,14 +974,16 @@ int pt_debug_read_queue(pt_ctx* ctx, uint32_t bounce, PtRay* host_rays, uint64_t
 }
 
 int pt_debug_read_bvh(pt_ctx* ctx, void* nodes, uint64_t node_capacity, void* tris, uint64_t tri_capacity, uint64_t* num_nodes,
-                      uint64_t* num_tris, float* scene_mag) {
+                      uint64_t* num_tris, float* scene_mag, uint32_t* record_bytes) {
   PT_REQUIRE_CTX();
   if (!ctx->has_scene) return ctx->fail(PT_ERR_NO_SCENE, "pt_debug_read_bvh before pt_scene_create");
 #if PT_NODE_STRIDE_U4 != 5
   return ctx->fail(PT_ERR_UNSUPPORTED, "pt_debug_read_bvh needs packed 80-byte nodes");
 #else
   const uint64_t nn = ctx->info.num_bvh_nodes;
-  const uint64_t nt = (ctx->info.bvh_bytes - nn * sizeof(PtBvh8Node)) / sizeof(PtTriRecord);
+  const uint64_t nt = ctx->num_records;
+  const size_t rb = ctx->ds.paired ? sizeof(PtPrimRecord) : sizeof(PtTriRecord);
+  if (record_bytes) *record_bytes = (uint32_t)rb;
   if (num_nodes) *num_nodes = nn;
   if (num_tris) *num_tris = nt;
   if (scene_mag) *scene_mag = ctx->ds.scene_mag;
@@ -986,7 +991,7 @@ int pt_debug_read_bvh(pt_ctx* ctx, void* nodes, uint64_t node_capacity, void* tr
   if (!nodes || !tris || node_capacity < nn || tri_capacity < nt) return ctx->fail(PT_ERR_INVALID_ARG, "pt_debug_read_bvh: arrays too small");
   PT_HIP(hipStreamSynchronize(ctx->stream));
   if (nn) PT_HIP(hipMemcpy(nodes, ctx->ds.nodes, nn * sizeof(PtBvh8Node), hipMemcpyDeviceToHost));
-  if (nt) PT_HIP(hipMemcpy(tris, ctx->ds.tris, nt * sizeof(PtTriRecord), hipMemcpyDeviceToHost));
+  if (nt) PT_HIP(hipMemcpy(tris, ctx->ds.tris, nt * rb, hipMemcpyDeviceToHost));
   return PT_OK;
 #endif
 }

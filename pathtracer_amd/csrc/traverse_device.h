@@ -48,14 +48,19 @@ struct TriTester {
     Sy = sel3(r.dx, r.dy, r.dz, ky) / dz;
     Sz = 1.0f / dz;
   }
-  __device__ __forceinline__ void test(const uint4& q0, const uint4& q1, const uint4& q2, float tmin, HitRec& best) const {
-    const float ax = __uint_as_float(q0.x) - ox, ay = __uint_as_float(q0.y) - oy, az = __uint_as_float(q0.z) - oz;
-    const float bx = __uint_as_float(q1.x) - ox, by = __uint_as_float(q1.y) - oy, bz = __uint_as_float(q1.z) - oz;
-    const float cx = __uint_as_float(q2.x) - ox, cy = __uint_as_float(q2.y) - oy, cz = __uint_as_float(q2.z) - oz;
-    const float Akz = sel3(ax, ay, az, kz), Bkz = sel3(bx, by, bz, kz), Ckz = sel3(cx, cy, cz, kz);
-    const float Ax = sel3(ax, ay, az, kx) - Sx * Akz, Ay = sel3(ax, ay, az, ky) - Sy * Akz;
-    const float Bx = sel3(bx, by, bz, kx) - Sx * Bkz, By = sel3(bx, by, bz, ky) - Sy * Bkz;
-    const float Cx = sel3(cx, cy, cz, kx) - Sx * Ckz, Cy = sel3(cx, cy, cz, ky) - Sy * Ckz;
+  // A vertex translated to the ray origin and sheared into the ray's frame: (x, y) in the plane across the ray, kz the
+  // component along its dominant axis.
+  struct Sheared { float x, y, kz; };
+  __device__ __forceinline__ Sheared shear(float vx, float vy, float vz) const {
+    const float ax = vx - ox, ay = vy - oy, az = vz - oz;
+    Sheared r;
+    r.kz = sel3(ax, ay, az, kz);
+    r.x = sel3(ax, ay, az, kx) - Sx * r.kz;
+    r.y = sel3(ax, ay, az, ky) - Sy * r.kz;
+    return r;
+  }
+  __device__ __forceinline__ void test_sheared(const Sheared& A, const Sheared& B, const Sheared& C, uint32_t prim, float tmin, HitRec& best) const {
+    const float Ax = A.x, Ay = A.y, Bx = B.x, By = B.y, Cx = C.x, Cy = C.y;
     float U = Cx * By - Cy * Bx;
     float V = Ax * Cy - Ay * Cx;
     float W = Bx * Ay - By * Ax;
@@ -73,18 +78,38 @@ struct TriTester {
     if ((U < 0.0f || V < 0.0f || W < 0.0f) && (U > 0.0f || V > 0.0f || W > 0.0f)) return;
     const float det = U + V + W;
     if (det == 0.0f) return;
-    const float Az = Sz * Akz, Bz = Sz * Bkz, Cz = Sz * Ckz;
+    const float Az = Sz * A.kz, Bz = Sz * B.kz, Cz = Sz * C.kz;
     const float T = U * Az + V * Bz + W * Cz;
     const float rcpDet = 1.0f / det;
     const float t = T * rcpDet;
     if (!(t > tmin)) return;
-    const uint32_t prim = q0.w;
     if (t < best.t || (t == best.t && best.prim != 0xFFFFFFFFu && prim < best.prim)) {  // t == tmax itself is not a hit
       best.t = t;
       best.u = V * rcpDet;
       best.v = W * rcpDet;
       best.prim = prim;
     }
+  }
+  __device__ __forceinline__ static Sheared pick(const Sheared& a, const Sheared& b, const Sheared& c, const Sheared& d, uint32_t i) {
+    const bool odd = (i & 1u) != 0u, high = (i & 2u) != 0u;
+    Sheared r;
+    r.x = high ? (odd ? d.x : c.x) : (odd ? b.x : a.x);
+    r.y = high ? (odd ? d.y : c.y) : (odd ? b.y : a.y);
+    r.kz = high ? (odd ? d.kz : c.kz) : (odd ? b.kz : a.kz);
+    return r;
+  }
+  // One primitive record (bvh8.h): triangle 0 = (v0, v1, v2); triangle 1, when present, picks its three vertices in its
+  // own order out of {v0, v1, v2, v3}. Each test is the stand-alone arithmetic of that triangle. Returns triangles tested.
+  __device__ __forceinline__ uint32_t test(const uint4& q0, const uint4& q1, const uint4& q2, const uint4& q3, float tmin, HitRec& best) const {
+    const Sheared A = shear(__uint_as_float(q0.x), __uint_as_float(q0.y), __uint_as_float(q0.z));
+    const Sheared B = shear(__uint_as_float(q1.x), __uint_as_float(q1.y), __uint_as_float(q1.z));
+    const Sheared C = shear(__uint_as_float(q2.x), __uint_as_float(q2.y), __uint_as_float(q2.z));
+    test_sheared(A, B, C, q0.w, tmin, best);
+    if (q1.w == 0xFFFFFFFFu) return 1u;
+    const Sheared D = shear(__uint_as_float(q3.x), __uint_as_float(q3.y), __uint_as_float(q3.z));
+    const uint32_t code = q2.w;
+    test_sheared(pick(A, B, C, D, code & 3u), pick(A, B, C, D, (code >> 2) & 3u), pick(A, B, C, D, (code >> 4) & 3u), q1.w, tmin, best);
+    return 2u;
   }
 };
 
@@ -314,16 +339,26 @@ struct Traverser {
     tg.y = hitmask & 0x00FFFFFFu;
   }
 
-  // Tests the lowest pending triangle of tg.
-  __device__ __forceinline__ void tri_step(const uint4* __restrict__ tris) {
+  // Tests the lowest pending record of tg. PAIRS: 64-byte records (one triangle, or two that share an edge); else 48-byte
+  // single-triangle records. Returns triangles tested.
+  template <bool PAIRS>
+  __device__ __forceinline__ uint32_t tri_step(const uint4* __restrict__ tris) {
     const int i = __ffs((int)tg.y) - 1;
     tg.y &= tg.y - 1u;
     const uint32_t ti = tg.x + (uint32_t)i;
+    if (PAIRS) {
+      const uint4* tp = (const uint4*)((const char*)tris + (ti << 6));   // 32-bit byte offset (< 4 GB of records)
+      const uint4 q0 = tp[0], q1 = tp[1], q2 = tp[2], q3 = tp[3];
+      return tt.test(q0, q1, q2, q3, ray.tmin, best);
+    }
     uint32_t toff;
-    asm("v_lshl_add_u32 %0, %1, 1, %1" : "=v"(toff) : "v"(ti));   // x3, then x16: 32-bit offset (< 4 GB of triangle records)
+    asm("v_lshl_add_u32 %0, %1, 1, %1" : "=v"(toff) : "v"(ti));   // x3, then x16 (asm: the compiler turns shift-adds into v_mul_lo_u32)
     const uint4* tp = (const uint4*)((const char*)tris + (toff << 4));
     const uint4 q0 = tp[0], q1 = tp[1], q2 = tp[2];
-    tt.test(q0, q1, q2, ray.tmin, best);
+    tt.test_sheared(tt.shear(__uint_as_float(q0.x), __uint_as_float(q0.y), __uint_as_float(q0.z)),
+                    tt.shear(__uint_as_float(q1.x), __uint_as_float(q1.y), __uint_as_float(q1.z)),
+                    tt.shear(__uint_as_float(q2.x), __uint_as_float(q2.y), __uint_as_float(q2.z)), q0.w, ray.tmin, best);
+    return 1u;
   }
 };
 

@@ -555,8 +555,10 @@ def test_courtyard_c5_10m_triangles_depth16_russian_roulette(ctx, oracle):
 
 
 # ---------------------------------------------------------------------------------------------- roofline inputs
-def test_count_kernel_matches_host_walker_on_the_same_bvh8(ctx, oracle):
-    """bench.py's roofline is built on nodes / triangles per ray reported by the COUNT instantiation of k_extend. A
+@pytest.mark.parametrize("pairs", [False, True], ids=["48-byte-triangles", "64-byte-pairs"])
+def test_count_kernel_matches_host_walker_on_the_same_bvh8(ctx, oracle, pairs):
+    """Both leaf-record formats of the builder (single triangles; edge-sharing pairs, its choice for scenes beyond the
+    Infinity Cache). bench.py's roofline is built on nodes / triangles per ray reported by the COUNT instantiation of k_extend. A
     second implementation (tests/walker/bvh8_walker.cpp: scalar host walker over the very BVH8 the device holds, read
     back with pt_debug_read_bvh, canonical schedule) must report the same totals and the same hit records."""
     import ctypes as C
@@ -566,16 +568,20 @@ def test_count_kernel_matches_host_walker_on_the_same_bvh8(ctx, oracle):
     wl = C.CDLL(so)
     P = C.c_void_p
     wl.bvh8_walk.restype = C.c_int
-    wl.bvh8_walk.argtypes = [P, C.c_uint64, P, C.c_uint64, C.c_float, P, C.c_uint64, P, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    wl.bvh8_walk.argtypes = [P, C.c_uint64, P, C.c_uint64, C.c_uint32, C.c_float, P, C.c_uint64, P, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     sc = scenes.atrium(1)
-    ctx.scene_create(sc)
+    ctx.scene_create(sc, api.PT_SCENE_PAIR_TRIANGLES if pairs else api.PT_SCENE_NO_PAIRS)
     info = ctx.scene_info()
     nodes, tris, mag = ctx.debug_read_bvh()
-    assert len(nodes) == info.num_bvh_nodes and len(tris) == info.num_triangles
+    assert len(nodes) == info.num_bvh_nodes and tris.shape[1] == (64 if pairs else 48)
+    if pairs:
+        assert info.num_triangles // 2 <= len(tris) < 0.6 * info.num_triangles   # made of quads: nearly every triangle finds its pair
+    else:
+        assert len(tris) == info.num_triangles
     rays = random_rays(77, 100000, list(info.bounds_min), list(info.bounds_max), tmin=0.001, tmax=10000.0)
     whits = np.empty(len(rays), dtype=api.HIT_DTYPE)
     cn, ct = C.c_uint64(), C.c_uint64()
-    assert wl.bvh8_walk(api.ptr(nodes), len(nodes), api.ptr(tris), len(tris), mag, api.ptr(rays), len(rays), api.ptr(whits),
+    assert wl.bvh8_walk(api.ptr(nodes), len(nodes), api.ptr(tris), len(tris), tris.shape[1], mag, api.ptr(rays), len(rays), api.ptr(whits),
                         C.byref(cn), C.byref(ct)) == 0
     try:
         ctx.set_option(api.PT_OPT_EXTEND_DEFER, 0)

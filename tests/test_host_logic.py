@@ -279,3 +279,58 @@ def test_image_io_roundtrip_and_png_signature(tmp_path):
     n = struct.unpack(">I", data[i - 4:i])[0]
     raw = zlib.decompress(data[i + 4:i + 4 + n])
     assert len(raw) == h * (1 + 3 * w)
+
+
+# ---------------------------------------------------------------------------------------------- BVH8 builder on the CPU
+def _flat_triangles(sc):
+    """Triangle list in primitive order for scenes whose instances carry no transform (InitRtScene order: instance by
+    instance, PathTracer.cpp:171-339)."""
+    out = []
+    for mesh, _, xf in sc.instances:
+        assert xf is None
+        v, idx = sc.meshes[mesh]
+        out.append(v["pos"][idx].reshape(-1, 9))
+    return np.ascontiguousarray(np.concatenate(out), dtype=np.float32)
+
+
+@pytest.mark.parametrize("scene", ["atrium", "soup+duplicates"])
+def test_bvh8_builder_both_leaf_formats_walk_to_the_oracle_hits(oracle, scene):
+    """The product's host-side builder (csrc/bvh_builder.cpp) run on the CPU, walked by tests/walker: 48-byte triangle
+    records and 64-byte edge-sharing pairs must give the oracle's hit records bit for bit (the pair test shears the
+    shared vertices once, which must not change a bit), and the paired hierarchy is the smaller one."""
+    so = os.path.join(ROOT, "tests", "walker", "libbvh8_walker.so")
+    assert os.path.exists(so), "build tests/walker first (__graft_entry__.build())"
+    wl = C.CDLL(so)
+    P = C.c_void_p
+    wl.bvh8_build_and_walk.restype = C.c_int
+    wl.bvh8_build_and_walk.argtypes = [P, C.c_uint32, C.c_int, P, C.c_uint64, P, P, P, P]
+    if scene == "atrium":
+        sc = scenes.atrium(1)
+        lo, hi, n_rays = (-20, 0, -10), (20, 16, 10), 30000
+    else:
+        sc = scenes.random_triangle_soup(5, 4000)
+        v, idx = sc.meshes[0]
+        # the same triangle three times (every edge shared by three records) and a sliver with two equal vertices
+        extra = np.zeros(12, dtype=api.VERTEX_DTYPE)
+        extra["pos"] = [[3, 1, 3], [4, 1, 3], [3, 1, 4]] * 3 + [[5, 5, 5], [5, 5, 5], [6, 5, 5]]
+        extra["normal"] = [0, 1, 0]
+        sc = SceneData([(np.concatenate([v, extra]), np.arange(len(v) + 12, dtype=np.uint32))], [(0, 0, None)], sc.materials)
+        lo, hi, n_rays = (0, 0, 0), (10, 10, 10), 30000
+    tris = _flat_triangles(sc)
+    from tests.common import random_rays
+    rays = random_rays(9, n_rays, lo, hi, tmin=0.001, tmax=1e4)
+    want = oracle.scene(sc).trace_rays(rays)
+    stats = {}
+    for mode in (0, 1):
+        hits = np.empty(len(rays), dtype=api.HIT_DTYPE)
+        cn, ct, info = np.zeros(1, np.uint64), np.zeros(1, np.uint64), np.zeros(5, np.uint64)
+        assert wl.bvh8_build_and_walk(api.ptr(tris), len(tris), mode, api.ptr(rays), len(rays), api.ptr(hits), api.ptr(cn), api.ptr(ct),
+                                      api.ptr(info)) == 0
+        assert np.array_equal(hits.view(np.uint32), want.view(np.uint32)), mode
+        stats[mode] = (int(info[0]), int(info[1]), int(info[2]), int(info[3]), int(cn[0]), int(ct[0]))
+    assert stats[0][1:4] == (len(tris), 0, 48) and stats[1][3] == 64
+    assert stats[1][1] + stats[1][2] == len(tris)                 # every triangle is in exactly one record
+    if scene == "atrium":
+        assert stats[1][2] > 0.45 * len(tris) and stats[1][0] < 0.8 * stats[0][0]     # quads pair up; fewer nodes
+    else:
+        assert 1 <= stats[1][2] <= 8                              # a random soup shares no edges; the duplicates do

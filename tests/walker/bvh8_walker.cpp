@@ -35,31 +35,45 @@ struct Tri {
     if (dz < 0.0f) { int t = kx; kx = ky; ky = t; }
     Sx = r.d[kx] / dz; Sy = r.d[ky] / dz; Sz = 1.0f / dz;
   }
-  void test(const PtTriRecord& T, float tmin, Hit& best) const {
-    const float A[3] = {T.v0[0] - o[0], T.v0[1] - o[1], T.v0[2] - o[2]};
-    const float B[3] = {T.v1[0] - o[0], T.v1[1] - o[1], T.v1[2] - o[2]};
-    const float C[3] = {T.v2[0] - o[0], T.v2[1] - o[1], T.v2[2] - o[2]};
-    const float Akz = A[kz], Bkz = B[kz], Ckz = C[kz];
-    const float Ax = A[kx] - Sx * Akz, Ay = A[ky] - Sy * Akz;
-    const float Bx = B[kx] - Sx * Bkz, By = B[ky] - Sy * Bkz;
-    const float Cx = C[kx] - Sx * Ckz, Cy = C[ky] - Sy * Ckz;
-    float U = Cx * By - Cy * Bx, V = Ax * Cy - Ay * Cx, W = Bx * Ay - By * Ax;
+  struct Sh { float x, y, kz; };
+  Sh shear(const float* v) const {
+    const float a[3] = {v[0] - o[0], v[1] - o[1], v[2] - o[2]};
+    Sh r;
+    r.kz = a[kz];
+    r.x = a[kx] - Sx * r.kz;
+    r.y = a[ky] - Sy * r.kz;
+    return r;
+  }
+  void test3(const Sh& A, const Sh& B, const Sh& C, uint32_t prim, float tmin, Hit& best) const {
+    float U = C.x * B.y - C.y * B.x, V = A.x * C.y - A.y * C.x, W = B.x * A.y - B.y * A.x;
     if (U == 0.0f || V == 0.0f || W == 0.0f) {
-      U = (float)((double)Cx * (double)By - (double)Cy * (double)Bx);
-      V = (float)((double)Ax * (double)Cy - (double)Ay * (double)Cx);
-      W = (float)((double)Bx * (double)Ay - (double)By * (double)Ax);
+      U = (float)((double)C.x * (double)B.y - (double)C.y * (double)B.x);
+      V = (float)((double)A.x * (double)C.y - (double)A.y * (double)C.x);
+      W = (float)((double)B.x * (double)A.y - (double)B.y * (double)A.x);
     }
     if ((U < 0.0f || V < 0.0f || W < 0.0f) && (U > 0.0f || V > 0.0f || W > 0.0f)) return;
     const float det = U + V + W;
     if (det == 0.0f) return;
-    const float Az = Sz * Akz, Bz = Sz * Bkz, Cz = Sz * Ckz;
+    const float Az = Sz * A.kz, Bz = Sz * B.kz, Cz = Sz * C.kz;
     const float Tt = U * Az + V * Bz + W * Cz;
     const float rcp = 1.0f / det;
     const float t = Tt * rcp;
     if (!(t > tmin)) return;
-    if (t < best.t || (t == best.t && best.prim != 0xFFFFFFFFu && T.prim < best.prim)) {
-      best.t = t; best.u = V * rcp; best.v = W * rcp; best.prim = T.prim;
+    if (t < best.t || (t == best.t && best.prim != 0xFFFFFFFFu && prim < best.prim)) {
+      best.t = t; best.u = V * rcp; best.v = W * rcp; best.prim = prim;
     }
+  }
+  // one primitive record: triangle 0 = (v0,v1,v2); triangle 1 picks its vertices out of {v0,v1,v2,v3} by the 2-bit codes
+  uint32_t test(const PtPrimRecord& T, float tmin, Hit& best) const {
+    const Sh s[4] = {shear(T.v0), shear(T.v1), shear(T.v2), shear(T.v3)};
+    test3(s[0], s[1], s[2], T.prim0, tmin, best);
+    if (T.prim1 == 0xFFFFFFFFu) return 1;
+    test3(s[T.code & 3u], s[(T.code >> 2) & 3u], s[(T.code >> 4) & 3u], T.prim1, tmin, best);
+    return 2;
+  }
+  uint32_t test(const PtTriRecord& T, float tmin, Hit& best) const {
+    test3(shear(T.v0), shear(T.v1), shear(T.v2), T.prim, tmin, best);
+    return 1;
   }
 };
 
@@ -71,8 +85,13 @@ inline float pow2_from_biased(uint8_t e) { uint32_t b = (uint32_t)e << 23; float
 static uint32_t* g_visit_hist = nullptr;   // optional: visits per node index (tools/exp_node_hist.py)
 extern "C" void bvh8_set_visit_hist(uint32_t* hist) { g_visit_hist = hist; }
 
-extern "C" int bvh8_walk(const PtBvh8Node* nodes, uint64_t num_nodes, const PtTriRecord* tris, uint64_t num_tris, float scene_mag,
-                         const Ray* rays, uint64_t n, Hit* hits, uint64_t* nodes_opened, uint64_t* tris_tested) {
+// records: num_tris leaf records of record_bytes each (48 = PtTriRecord, 64 = PtPrimRecord)
+extern "C" int bvh8_walk(const PtBvh8Node* nodes, uint64_t num_nodes, const void* records, uint64_t num_tris, uint32_t record_bytes,
+                         float scene_mag, const Ray* rays, uint64_t n, Hit* hits, uint64_t* nodes_opened, uint64_t* tris_tested) {
+  if (record_bytes != sizeof(PtTriRecord) && record_bytes != sizeof(PtPrimRecord)) return -3;
+  const bool paired = record_bytes == sizeof(PtPrimRecord);
+  const PtPrimRecord* prims = static_cast<const PtPrimRecord*>(records);
+  const PtTriRecord* tris = static_cast<const PtTriRecord*>(records);
   uint64_t cn = 0, ct = 0;
   std::vector<std::pair<uint32_t, uint32_t>> stack;
   for (uint64_t i = 0; i < n; ++i) {
@@ -130,8 +149,7 @@ extern "C" int bvh8_walk(const PtBvh8Node* nodes, uint64_t num_nodes, const PtTr
           tb &= tb - 1u;
           const uint64_t ti = (uint64_t)nd.tri_base + (uint32_t)k;
           if (ti >= num_tris) return -2;
-          ++ct;
-          tt.test(tris[ti], r.tmin, best);
+          ct += paired ? tt.test(prims[ti], r.tmin, best) : tt.test(tris[ti], r.tmin, best);
         }
       } else if (!stack.empty()) {
         gbase = stack.back().first; gbits = stack.back().second;
@@ -145,4 +163,19 @@ extern "C" int bvh8_walk(const PtBvh8Node* nodes, uint64_t num_nodes, const PtTr
   }
   *nodes_opened = cn; *tris_tested = ct;
   return 0;
+}
+
+// CPU-only check of the product's host-side builder (pathtracer_amd/csrc/bvh_builder.cpp is plain C++): build from a
+// triangle list (9 floats each) in the given leaf format (0 = 48-byte triangles, 1 = 64-byte pairs, -1 = builder's choice)
+// and walk it. info = {nodes, records, pairs, record_bytes, max_depth}.
+#include "../../pathtracer_amd/csrc/bvh_builder.h"
+extern "C" int bvh8_build_and_walk(const float* verts, uint32_t num_tris, int pair_mode, const Ray* rays, uint64_t n, Hit* hits,
+                                   uint64_t* nodes_opened, uint64_t* tris_tested, uint64_t* info) {
+  pt::Bvh8 b;
+  pt::build_bvh8(verts, num_tris, b, 4, pair_mode);
+  float mag = 0.0f;
+  for (int a = 0; a < 3; ++a) mag = std::fmax(mag, std::fmax(std::fabs(b.lo[a]), std::fabs(b.hi[a])));
+  info[0] = b.nodes.size(); info[1] = b.num_records(); info[2] = b.num_pairs; info[3] = b.record_bytes(); info[4] = b.max_depth;
+  return bvh8_walk(b.nodes.data(), b.nodes.size(), b.records(), b.num_records(), (uint32_t)b.record_bytes(), mag, rays, n, hits,
+                   nodes_opened, tris_tested);
 }

@@ -13,7 +13,7 @@ scene, cam, depth = {"atrium": (scenes.atrium, scenes.ATRIUM_CAM, 4), "street": 
 wlk = C.CDLL(os.path.join(ROOT, "tests", "walker", "libbvh8_walker.so"))
 P = C.c_void_p
 wlk.bvh8_walk.restype = C.c_int
-wlk.bvh8_walk.argtypes = [P, C.c_uint64, P, C.c_uint64, C.c_float, P, C.c_uint64, P, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+wlk.bvh8_walk.argtypes = [P, C.c_uint64, P, C.c_uint64, C.c_uint32, C.c_float, P, C.c_uint64, P, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
 wlk.bvh8_set_visit_hist.argtypes = [P]
 from pathtracer_amd import Context
 ctx = Context(0)
@@ -39,7 +39,7 @@ for b in (depth - 1, depth):                 # the last two bounce queues are in
         continue
     hits = np.empty(len(rays), dtype=api.HIT_DTYPE)
     cn, ct = C.c_uint64(), C.c_uint64()
-    assert wlk.bvh8_walk(api.ptr(nodes), len(nodes), api.ptr(tris), len(tris), mag, api.ptr(rays), len(rays), api.ptr(hits), C.byref(cn), C.byref(ct)) == 0
+    assert wlk.bvh8_walk(api.ptr(nodes), len(nodes), api.ptr(tris), len(tris), tris.shape[1], mag, api.ptr(rays), len(rays), api.ptr(hits), C.byref(cn), C.byref(ct)) == 0
     tot_rays += len(rays)
     print(f"bounce {b}: {len(rays)} rays, {cn.value / len(rays):.2f} nodes/ray, {ct.value / len(rays):.2f} tris/ray")
 tot = hist.sum()
