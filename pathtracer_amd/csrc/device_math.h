@@ -40,6 +40,48 @@ __device__ __forceinline__ float hlsl_pow(float x, float y) {
   return powf(x, y);
 }
 
+// ---- the hardware transcendental unit -----------------------------------------------------------------------------------
+// HLSL sin / cos / pow compile to the GPU's transcendental instructions on the reference's target too; here the hot
+// shading path uses CDNA's directly instead of OCML's software routines (range reduction with a Payne-Hanek slow path,
+// extended-precision pow: some 50-120 instructions each). Measured exhaustively over all 2^23 values GetRand01 can
+// return (tools/hwmath/hwmath.hip): v_sin_f32 / v_cos_f32 abs error <= 1.26e-7; exp2(y*log2(x)) rel error <= 7.9e-6
+// for results >= 1e-30. tests: test_shading_functions_match_oracle_and_fixture (rtol 2e-5 .. 5e-5 vs the libm oracle).
+// PT_SHADE_LIBM_FORMS=1 builds the OCML forms back in (bisecting).
+#ifndef PT_SHADE_LIBM_FORMS
+#define PT_SHADE_LIBM_FORMS 0
+#endif
+// sin(2 pi u), cos(2 pi u): v_sin_f32 / v_cos_f32 take their argument in revolutions
+__device__ __forceinline__ float sin_2pi(float u) { return PT_SHADE_LIBM_FORMS ? sinf(6.28318530717958647692f * u) : __builtin_amdgcn_sinf(u); }
+__device__ __forceinline__ float cos_2pi(float u) { return PT_SHADE_LIBM_FORMS ? cosf(6.28318530717958647692f * u) : __builtin_amdgcn_cosf(u); }
+// hlsl_pow with the same edge cases, core = v_exp_f32(y * v_log_f32(x))
+__device__ __forceinline__ float hlsl_pow_hw(float x, float y) {
+  if (PT_SHADE_LIBM_FORMS) return hlsl_pow(x, y);
+  float r = __builtin_amdgcn_exp2f(y * __builtin_amdgcn_logf(x));   // x < 0: NaN; x == 0, y > 0: exp2(-inf) = 0; y < 0: inf
+  r = y == 0.0f ? 1.0f : r;                                          // 0 * -inf
+  return x < 0.0f ? __builtin_nanf("") : r;
+}
+// hlsl_pow(x, 5) by multiplication (4 roundings; NaN for x < 0 as the intrinsic)
+__device__ __forceinline__ float hlsl_pow5(float x) {
+  if (PT_SHADE_LIBM_FORMS) return hlsl_pow(x, 5.0f);
+  const float x2 = x * x;
+  const float r = x2 * x2 * x;
+  return x < 0.0f ? __builtin_nanf("") : r;
+}
+
+// n / d and n % d for a wave-uniform divisor through one float multiply and one correction step: exact while the
+// quotient stays below 2^20 (pixel rows, samples of a batch); replaces four ~25-instruction 32-bit divisions per path.
+struct FastDiv {
+  uint32_t d;
+  float inv;
+  __device__ __forceinline__ explicit FastDiv(uint32_t div) : d(div), inv(1.0f / (float)div) {}
+  __device__ __forceinline__ void divmod(uint32_t n, uint32_t& q, uint32_t& r) const {
+    q = (uint32_t)((float)n * inv);
+    r = n - q * d;
+    if ((int32_t)r < 0) { --q; r += d; }
+    else if (r >= d) { ++q; r -= d; }
+  }
+};
+
 #define PT_PI 3.14159265358979323846f
 #define PT_TWO_PI 6.28318530717958647692f
 

@@ -95,8 +95,9 @@ __global__ void __launch_bounds__(256) k_generate(PtRtConsts c, float4* __restri
   if (p == 0) counters[CTR_AT(CTR_QCOUNT0)] = n_paths;
   if (p >= n_paths) return;
   const uint32_t wh = w * h;
-  const uint32_t pix = p % wh, si = p / wh;
-  const uint32_t px = pix % w, py = pix / w;
+  uint32_t pix, si, px, py;
+  FastDiv(wh).divmod(p, si, pix);
+  FastDiv(w).divmod(pix, py, px);
   Rng rng = InitRNG(px, py, first_sample + si);
   // PathTracing.hlsl:47-51 with the Q1 deviation: position = uPixel + jitter, jitter in [0,1)^2
   v2 pixel;
@@ -333,6 +334,7 @@ __global__ void __launch_bounds__(PT_SHADE_THREADS, PT_SHADE_MIN_WAVES) k_shade(
   const bool last_bounce = (uint32_t)bounce >= c.myMaxRecursionDepth;
   const uint32_t wh = w * h;
   uint32_t shaded_local = 0u, miss_local = 0u;
+  const FastDiv div_wh(wh), div_w(w);
   int parity = 0;
   for (uint32_t j0 = blockIdx.x * blockDim.x; j0 < n; j0 += gridDim.x * blockDim.x, parity ^= 1) {  // block-uniform trip count
     const uint32_t j = j0 + threadIdx.x;
@@ -396,8 +398,10 @@ __global__ void __launch_bounds__(PT_SHADE_THREADS, PT_SHADE_MIN_WAVES) k_shade(
         float4 Ts = st_T[pid];
         v3 transmission = mk3(Ts.x, Ts.y, Ts.z);
         Rng rng;
-        const uint32_t pix = pid % wh;
-        rng.x = pix % w; rng.y = pix / w; rng.z = first_sample + pid / wh; rng.w = __float_as_uint(Ts.w);
+        uint32_t pix, si;
+        div_wh.divmod(pid, si, pix);
+        div_w.divmod(pix, rng.y, rng.x);
+        rng.z = first_sample + si; rng.w = __float_as_uint(Ts.w);
         const float specularStrength = 0.9f;
         const float specularPower = c.myPhongSpecularPower;
         const v3 V = -dir;
@@ -407,11 +411,14 @@ __global__ void __launch_bounds__(PT_SHADE_THREADS, PT_SHADE_MIN_WAVES) k_shade(
         } else {
         const float fresnel = GetFresnelSchlick(hitNormal, V);
         const float specRayProbability = EstimateSpecularRayProbability(specularStrength, color, fresnel);
-        if (GetRand01(rng) < specRayProbability) {
+        // the three draws are the same sequence on both sides of the branch (:86, then two in either sampler): taken
+        // before it, so that a wave whose lanes split runs the generator once
+        const float pick = GetRand01(rng);
+        v2 u;
+        u.x = GetRand01(rng);
+        u.y = GetRand01(rng);
+        if (pick < specRayProbability) {
           float pdf;
-          v2 u;
-          u.x = GetRand01(rng);
-          u.y = GetRand01(rng);
           const v3 nextSampleDir = SampleModifiedPhong(u, hitNormal, specularPower, pdf);
           const v3 brdf = mk3(fresnel * EvaluateModifiedPhong(hitNormal, nextSampleDir, V, specularStrength, specularPower));
           transmission = transmission * (brdf / fmaxf(0.01f, pdf));
@@ -422,9 +429,6 @@ __global__ void __launch_bounds__(PT_SHADE_THREADS, PT_SHADE_MIN_WAVES) k_shade(
           const float pdf = GetLambertianPDF(hitNormal, V);
           transmission = transmission * (brdf / pdf);
           transmission = transmission / (1.0f - specRayProbability);
-          v2 u;
-          u.x = GetRand01(rng);
-          u.y = GetRand01(rng);
           newDir = GetCosineWeightedHemisphereDirection(u, hitNormal);
         }
         }
@@ -567,8 +571,10 @@ __global__ void __launch_bounds__(256) k_ao_rays(PtRtConsts c, DeviceScene sc, c
     const v3 hitNormal = bu * mk3(n0.x, n0.y, n0.z) + bv * mk3(n1.x, n1.y, n1.z) + baryZ * mk3(n2.x, n2.y, n2.z);
     const v3 hitPos = mk3(ro.x, ro.y, ro.z) + mk3(rd.x, rd.y, rd.z) * hr.x;
     Rng rng;
-    const uint32_t pix = pid % wh;
-    rng.x = pix % w; rng.y = pix / w; rng.z = first_sample + pid / wh; rng.w = 2u + 2u * i;
+    uint32_t pix, si;
+    FastDiv(wh).divmod(pid, si, pix);
+    FastDiv(w).divmod(pix, rng.y, rng.x);
+    rng.z = first_sample + si; rng.w = 2u + 2u * i;
     v2 rand11;
     rand11.x = GetRand01(rng) * 2.0f - 1.0f;
     rand11.y = GetRand01(rng) * 2.0f - 1.0f;

@@ -51,13 +51,21 @@ __device__ __forceinline__ float GetLuminance(v3 c) { return dot(c, mk3(0.2126f,
 __device__ __forceinline__ float GetFresnelSchlick(v3 N, v3 V) {
   const float f0 = 0.04f;
   float cosTheta = fmaxf(0.0f, dot(N, V));
-  return saturate(f0 + (1.0f - f0) * hlsl_pow(1.0f - cosTheta, 5.0f));
+  return saturate(f0 + (1.0f - f0) * hlsl_pow5(1.0f - cosTheta));
 }
 // GetUniformRandomDirectionInSphere — Common.hlsl:129-135
+// theta = 2 acos(sqrt(1 - u.y)) is evaluated through the half-angle identities: cos(theta) = 2 (1 - u.y) - 1 = 1 - 2 u.y,
+// sin(theta) = 2 sqrt(u.y) sqrt(1 - u.y) — the same real-valued function without acos and two of the four sin/cos (and
+// without the cancellation acos has near 1); phi's sin/cos come from the hardware unit (device_math.h).
 __device__ __forceinline__ v3 GetUniformRandomDirectionInSphere(v2 u) {
-  float phi = 2.0f * PT_PI * u.x;
-  float theta = 2.0f * acosf(sqrtf(1.0f - u.y));
-  return mk3(sinf(theta) * cosf(phi), sinf(theta) * sinf(phi), cosf(theta));
+  if (PT_SHADE_LIBM_FORMS) {
+    float phi = 2.0f * PT_PI * u.x;
+    float theta = 2.0f * acosf(sqrtf(1.0f - u.y));
+    return mk3(sinf(theta) * cosf(phi), sinf(theta) * sinf(phi), cosf(theta));
+  }
+  const float sinTheta = 2.0f * sqrtf(u.y * (1.0f - u.y));
+  const float cosTheta = 1.0f - 2.0f * u.y;
+  return mk3(sinTheta * cos_2pi(u.x), sinTheta * sin_2pi(u.x), cosTheta);
 }
 // GetCosineWeightedHemisphereDirection — Common.hlsl:137-141
 __device__ __forceinline__ v3 GetCosineWeightedHemisphereDirection(v2 u, v3 N) {
@@ -86,15 +94,14 @@ __device__ __forceinline__ float GetLambertianPDF(v3 N, v3 L) { return fmaxf(0.0
 __device__ __forceinline__ float EvaluateModifiedPhong(v3 N, v3 L, v3 V, float specularStrength, float specularPower) {
   v3 R = normalize(reflect(-L, N));
   float cosAlpha = fmaxf(0.0f, dot(R, V));
-  return specularStrength * ((specularPower + 2.0f) / PT_TWO_PI) * hlsl_pow(cosAlpha, specularPower) * fmaxf(0.0f, dot(N, L));
+  return specularStrength * ((specularPower + 2.0f) / PT_TWO_PI) * hlsl_pow_hw(cosAlpha, specularPower) * fmaxf(0.0f, dot(N, L));
 }
 // SampleModifiedPhong — brdfSampling.hlsl:24-39
 __device__ __forceinline__ v3 SampleModifiedPhong(v2 u, v3 N, float specularPower, float& pdf) {
-  float cosTheta = hlsl_pow(1.0f - u.x, 1.0f / (2.0f + specularPower));
+  float cosTheta = hlsl_pow_hw(1.0f - u.x, 1.0f / (2.0f + specularPower));
   float sinTheta = sqrtf(1.0f - cosTheta * cosTheta);
-  float phi = PT_TWO_PI * u.y;
-  pdf = ((specularPower + 2.0f) / PT_TWO_PI) * hlsl_pow(cosTheta, specularPower);
-  v3 d = mk3(cosf(phi) * sinTheta, cosTheta, sinf(phi) * sinTheta);
+  pdf = ((specularPower + 2.0f) / PT_TWO_PI) * hlsl_pow_hw(cosTheta, specularPower);
+  v3 d = mk3(cos_2pi(u.y) * sinTheta, cosTheta, sin_2pi(u.y) * sinTheta);   // phi = 2 pi u.y
   return TransformToNormalFrame(N, d);
 }
 // EstimateSpecularRayProbability — brdfSampling.hlsl:41-49

@@ -790,7 +790,10 @@ def test_ggx_and_pattern_functions_match_oracle(ctx, oracle):
     assert np.array_equal(d[:, 7], o[:, 7])
     same = d[:, 0] == o[:, 0]                       # alive flag: may flip only for directions grazing the surface
     assert same.mean() > 0.9995
-    np.testing.assert_allclose(d[same, 1:7], o[same, 1:7], rtol=5e-5, atol=2e-6)
+    np.testing.assert_allclose(d[same, 1:4], o[same, 1:4], rtol=5e-5, atol=2e-6)      # throughput weight
+    # direction: components of a unit vector near 0 — the atol of test_shading_functions_match_oracle_and_fixture (the
+    # diffuse lobe is GetCosineWeightedHemisphereDirection, whose libm form in the oracle loses ~3e-8/sqrt(u.y) to acos)
+    np.testing.assert_allclose(d[same, 4:7], o[same, 4:7], rtol=5e-5, atol=1e-5)
 
 
 def test_material_extension_image_matches_oracle(ctx, oracle):
