@@ -68,13 +68,17 @@ __device__ __forceinline__ float hlsl_pow5(float x) {
   return x < 0.0f ? __builtin_nanf("") : r;
 }
 
-// n / d and n % d for a wave-uniform divisor through one float multiply and one correction step: exact while the
-// quotient stays below 2^20 (pixel rows, samples of a batch); replaces four ~25-instruction 32-bit divisions per path.
+// n / d and n % d for a wave-uniform divisor through one float multiply and one correction step; replaces four
+// ~25-instruction 32-bit divisions per path. The float estimate is within 1 of the quotient while the quotient stays
+// below 2^20 (float(n) and 1/d carry 2^-24 each); n_max is the caller's bound on n, and a divisor too small for that
+// (1-pixel-wide targets, 1x1 targets with millions of samples) takes the integer division instead (wave-uniform).
 struct FastDiv {
   uint32_t d;
   float inv;
-  __device__ __forceinline__ explicit FastDiv(uint32_t div) : d(div), inv(1.0f / (float)div) {}
+  bool exact_path;
+  __device__ __forceinline__ FastDiv(uint32_t div, uint32_t n_max) : d(div), inv(1.0f / (float)div), exact_path(((uint64_t)div << 20) <= (uint64_t)n_max) {}
   __device__ __forceinline__ void divmod(uint32_t n, uint32_t& q, uint32_t& r) const {
+    if (exact_path) { q = n / d; r = n - q * d; return; }
     q = (uint32_t)((float)n * inv);
     r = n - q * d;
     if ((int32_t)r < 0) { --q; r += d; }

@@ -96,8 +96,8 @@ __global__ void __launch_bounds__(256) k_generate(PtRtConsts c, float4* __restri
   if (p >= n_paths) return;
   const uint32_t wh = w * h;
   uint32_t pix, si, px, py;
-  FastDiv(wh).divmod(p, si, pix);
-  FastDiv(w).divmod(pix, py, px);
+  FastDiv(wh, n_paths).divmod(p, si, pix);
+  FastDiv(w, wh).divmod(pix, py, px);
   Rng rng = InitRNG(px, py, first_sample + si);
   // PathTracing.hlsl:47-51 with the Q1 deviation: position = uPixel + jitter, jitter in [0,1)^2
   v2 pixel;
@@ -334,7 +334,7 @@ __global__ void __launch_bounds__(PT_SHADE_THREADS, PT_SHADE_MIN_WAVES) k_shade(
   const bool last_bounce = (uint32_t)bounce >= c.myMaxRecursionDepth;
   const uint32_t wh = w * h;
   uint32_t shaded_local = 0u, miss_local = 0u;
-  const FastDiv div_wh(wh), div_w(w);
+  const FastDiv div_wh(wh, 0x7fffffffu), div_w(w, wh);   // path ids stay below 2^31 (pt_api.cpp batch sizing)
   int parity = 0;
   for (uint32_t j0 = blockIdx.x * blockDim.x; j0 < n; j0 += gridDim.x * blockDim.x, parity ^= 1) {  // block-uniform trip count
     const uint32_t j = j0 + threadIdx.x;
@@ -572,8 +572,8 @@ __global__ void __launch_bounds__(256) k_ao_rays(PtRtConsts c, DeviceScene sc, c
     const v3 hitPos = mk3(ro.x, ro.y, ro.z) + mk3(rd.x, rd.y, rd.z) * hr.x;
     Rng rng;
     uint32_t pix, si;
-    FastDiv(wh).divmod(pid, si, pix);
-    FastDiv(w).divmod(pix, rng.y, rng.x);
+    FastDiv(wh, 0x7fffffffu).divmod(pid, si, pix);
+    FastDiv(w, wh).divmod(pix, rng.y, rng.x);
     rng.z = first_sample + si; rng.w = 2u + 2u * i;
     v2 rand11;
     rand11.x = GetRand01(rng) * 2.0f - 1.0f;

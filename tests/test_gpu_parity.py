@@ -278,9 +278,11 @@ def test_coincident_geometry_resolves_ties_to_the_lower_triangle_id(ctx, oracle)
     assert np.array_equal(got["t"].view(np.uint32), ref["t"].view(np.uint32))
 
 
-@pytest.mark.parametrize("w,h,spp", [(1, 1, 3), (67, 3, 5), (3, 129, 2), (65, 65, 1)])
+@pytest.mark.parametrize("w,h,spp", [(1, 1, 3), (67, 3, 5), (3, 129, 2), (65, 65, 1), (2048, 1, 2), (2049, 1, 2), (1, 1100000, 1),
+                                     (1, 1, 3000)])
 def test_odd_frame_sizes_match_oracle(ctx, cornell, w, h, spp):
-    """Frame sizes that are not multiples of the wave or block size, down to a single pixel."""
+    """Frame sizes that are not multiples of the wave or block size, down to a single pixel; the last four sit on both
+    sides of the switch between the float-reciprocal and the integer pixel decode (device_math.h FastDiv)."""
     sc, osc = cornell
     ctx.scene_create(sc)
     c = cornell_consts(w, h, sky=False, fallback=100.0)
@@ -291,8 +293,13 @@ def test_odd_frame_sizes_match_oracle(ctx, cornell, w, h, spp):
     st = ctx.stats()
     acc, ost, _ = osc.render(c, w, h, 2, spp)
     assert n == spp and st.samples == w * h * spp
-    assert (st.rays, st.shaded_hits, st.sky_misses) == (ost["rays"], ost["shaded_hits"], ost["sky_misses"])
-    assert rel_mse(img, acc) < 1e-8
+    if w * h * spp < 100000:
+        assert (st.rays, st.shaded_hits, st.sky_misses) == (ost["rays"], ost["shaded_hits"], ost["sky_misses"])
+        assert rel_mse(img, acc) < 1e-8
+    else:   # a million paths: a handful graze an edge where the last bit of a sampled direction decides (libm vs GPU sin/cos/pow)
+        for a, b in ((st.rays, ost["rays"]), (st.shaded_hits, ost["shaded_hits"]), (st.sky_misses, ost["sky_misses"])):
+            assert abs(a - b) <= 5e-5 * b, (a, b)
+        assert rel_mse(img, acc) < 1e-4
     hits = ctx.primary_hits(c, w, h, 2)
     assert np.array_equal(hits["prim"], osc.primary_hits(c, w, h, 2)["prim"])
 
