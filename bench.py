@@ -53,7 +53,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
-    ap.add_argument("--spp-per-step", type=int, default=16,
+    ap.add_argument("--spp-per-step", type=int, default=64,
                     help="samples per pixel rendered by one step (one pt_render call = one wavefront batch)")
     ap.add_argument("--depth", type=int, default=-1, help="myMaxRecursionDepth (default: the workload's)")
     ap.add_argument("--workload", default="atrium", choices=["atrium", "street", "courtyard", "cornell"])

@@ -1061,6 +1061,34 @@ def test_full_size_properties_1080p(ctx, oracle):
 
 
 # ---------------------------------------------------------------------------------------------- API behaviour
+def test_default_batch_shrinks_when_device_memory_is_short():
+    """The default wavefront batch is 2^27 paths (20 GB). When that much device memory is not free, pt_render halves the
+    batch until it fits instead of failing, and the image does not depend on the batch size."""
+    import torch
+    from pathtracer_amd.context import Context
+    cx = Context(0)
+    hold = None
+    try:
+        cx.scene_create(scenes.cornell_box())
+        w = h = 1024
+        spp = 128                                  # 2^27 paths at this size
+        c = cornell_consts(w, h, sky=False, fallback=1.0)
+        cx.set_option(api.PT_OPT_SAMPLES_PER_BATCH, 8)
+        cx.accum_reset(w, h)
+        cx.render(c, w, h, 0, spp)
+        ref = cx.accum_read_sum()[0]
+        cx.set_option(api.PT_OPT_SAMPLES_PER_BATCH, 0)
+        free, _ = torch.cuda.mem_get_info(0)
+        hold = torch.empty(max(0, free - (6 << 30)), dtype=torch.uint8, device="cuda:0")    # leave 6 GB + the old buffers
+        cx.accum_reset(w, h)
+        cx.render(c, w, h, 0, spp)                 # 20 GB and 10 GB do not fit, 5 GB does
+        got = cx.accum_read_sum()[0]
+        assert rel_mse(got, ref) < 1e-12
+    finally:
+        del hold
+        cx.close()
+
+
 def test_api_call_sequences_with_reallocation(oracle):
     """One context driven through scene replacement, target resizes (growing and shrinking wavefront state), both
     pipelines, both lanes and option changes; every stage is checked against the oracle."""

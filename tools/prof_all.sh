@@ -11,6 +11,6 @@ bash tools/prof_pmc.sh ${TAG}_atrium || exit 1
 python3 tools/summarize_pmc.py ${TAG}_atrium > gpurun_out/pmc_${TAG}_atrium_summary.txt
 bash tools/prof_pmc.sh ${TAG}_street --workload street || exit 1
 python3 tools/summarize_pmc.py ${TAG}_street > gpurun_out/pmc_${TAG}_street_summary.txt
-bash tools/prof_pmc.sh ${TAG}_courtyard --workload courtyard --width 3840 --height 2160 --spp-per-step 4 || exit 1
+bash tools/prof_pmc.sh ${TAG}_courtyard --workload courtyard --width 3840 --height 2160 --spp-per-step 16 || exit 1
 python3 tools/summarize_pmc.py ${TAG}_courtyard > gpurun_out/pmc_${TAG}_courtyard_summary.txt
 echo "all ok"
