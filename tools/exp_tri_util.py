@@ -1,0 +1,35 @@
+"""Triangle-phase lane utilisation against extend rate: sweeps the deferred schedule's thresholds (postpone %, continue %,
+queue depth) on one workload. Utilisation = lanes with work per wave-step, from the COUNT instantiation; rate from HIP
+events around the ordinary kernel. usage: python tools/exp_tri_util.py [atrium|street]"""
+import sys, os
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from pathtracer_amd import PathTracer, api, scenes
+
+wl = sys.argv[1] if len(sys.argv) > 1 else "atrium"
+W, H, SPP = 1920, 1080, 8
+scene, cam, depth = {"atrium": (scenes.atrium, scenes.ATRIUM_CAM, 4), "street": (scenes.street, scenes.STREET_CAM, 8)}[wl]
+pt = PathTracer(0, W, H); pt.myHalfResRender = False; pt.UpdateOutputTexture()
+pt.LoadScene(scene(), cam["eye"]); pt.myCamera.LookAt(cam["eye"], cam["target"])
+pt.mySampleSky = True; pt.myLightInstanceIdx = -1; pt.myMaxRecursionDepth = depth
+pt.mySky.ComputeTranmittanceLut(); pt._sky_dirty = False
+c = pt.BuildRtConsts(); ctx = pt.ctx
+ctx.set_option(api.PT_OPT_SAMPLES_PER_BATCH, SPP)
+grid = [(50, 25, 4), (50, 50, 4), (75, 50, 4), (75, 75, 4), (90, 75, 4), (50, 25, 6), (75, 75, 6), (90, 90, 6), (25, 10, 4), (0, 0, 4)]
+rows = []
+for (post, cont, defer) in grid:
+    ctx.set_option(api.PT_OPT_EXTEND_POSTPONE_PCT, post); ctx.set_option(api.PT_OPT_EXTEND_CONTINUE_PCT, cont); ctx.set_option(api.PT_OPT_EXTEND_DEFER, defer)
+    ctx.set_option(api.PT_OPT_COUNT_TRAVERSAL, 1); ctx.stats_reset()
+    ctx.render(c, W, H, 0, SPP)
+    s = ctx.stats()
+    ctx.set_option(api.PT_OPT_COUNT_TRAVERSAL, 0)
+    nu, tu = s.nodes_visited / (64.0 * s.node_wave_steps), s.tris_tested / (64.0 * s.tri_wave_steps)
+    npr, tpr = s.nodes_visited / s.rays, s.tris_tested / s.rays
+    rates = []
+    ctx.set_option(api.PT_OPT_TIME_KERNELS, 1)
+    for rep in range(3):
+        ctx.stats_reset(); ctx.render(c, W, H, 0, 2 * SPP); t = ctx.stats()
+        rates.append(t.rays / t.extend_ms / 1e3)
+    ctx.set_option(api.PT_OPT_TIME_KERNELS, 0)
+    rows.append((post, cont, defer, nu, tu, npr, tpr, float(np.median(rates))))
+    print(f"postpone {post:3d}%  continue {cont:3d}%  queue {defer}:  node-phase util {nu:.3f}  tri-phase util {tu:.3f}  nodes/ray {npr:6.2f}  tris/ray {tpr:5.2f}  extend {np.median(rates):8.1f} Mrays/s", flush=True)
