@@ -295,6 +295,15 @@ struct Traverser {
       asm volatile("" ::"v"(d));
     }
 #endif
+#ifdef PT_EXP_EXTRA_SALU   // experiment: N more scalar ALU instructions (register adds) per node step: what does the scalar pipe cost?
+    {
+      uint32_t d = 1u;
+      asm volatile("s_mov_b32 %0, 1" : "=s"(d));
+#pragma unroll
+      for (int k = 0; k < PT_EXP_EXTRA_SALU; ++k) asm volatile("s_add_u32 %0, %0, %0" : "+s"(d) : : "scc");
+      asm volatile("" ::"s"(d));
+    }
+#endif
 #ifdef PT_EXP_EXTRA_LOADS   // experiment: the same 16-byte reads again (L1 hits, one landing register): what does an L1 access cost?
     {
       typedef unsigned int u4v __attribute__((ext_vector_type(4)));
