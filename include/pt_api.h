@@ -206,6 +206,9 @@ enum {
                                       a commented-out, biased sketch at PathTracing.hlsl:110-124) */
   PT_OPT_EXTEND_TOP_NODES = 12,    /* tuning: BVH nodes (breadth-first order, i.e. the top of the tree) that every traversal block keeps in LDS */
   PT_OPT_EXTEND_CONTINUE_PCT = 13, /* tuning: a triangle phase of the deferred schedule continues while >= this % of busy lanes have work */
+  PT_OPT_FUSED_PRIMARY = 14,       /* 0/1 (default 1): pt_render computes primary rays inside the traversal and shading kernels
+                                      (RayGen's ray set-up, PathTracing.hlsl:40-61) instead of writing them to the bounce-0 queue
+                                      and reading them back: 160 B of memory traffic per path less, results bit-identical */
   PT_OPT_PIPELINE = 11             /* 0/1 (default 0): split every batch of >= 2 samples into two halves that run on two streams (the
                                       second one internal): one half's shade kernels and kernel drains run under the other half's
                                       extend, +2..5 % throughput, results bit-identical; off by default because concurrent kernels

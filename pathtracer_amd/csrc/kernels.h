@@ -50,7 +50,8 @@ struct WavefrontBuffers {
   float4* st_T = nullptr;                 // throughput.xyz, rng draw counter bits
   float4* st_L = nullptr;                 // luminance.xyz, -
   float4* sky_o = nullptr;                // ray origin.xyz, path id bits
-  float4* sky_d = nullptr;                // ray dir.xyz, -
+  float4* sky_d = nullptr;                // ray dir.xyz, 1 = primary of a fused batch (state still the initial constants)
+  float4* gen = nullptr;                  // 4 x float4: the primary-ray frame of the batch (k_primary_setup)
   uint32_t* counters = nullptr;           // CTR_WORDS
   unsigned long long* stats = nullptr;    // ST_WORDS
   uint64_t capacity = 0;                  // paths
@@ -82,8 +83,11 @@ struct LaunchCfg {
 void launch_transmittance_lut(const PtAtmosphere& atm, uint2* lut, hipStream_t s);
 void launch_generate(const PtRtConsts& c, const WavefrontBuffers& wb, uint32_t w, uint32_t h, uint32_t first_sample,
                      uint32_t samples_in_batch, hipStream_t s);
+void launch_primary_setup(const PtRtConsts& c, const WavefrontBuffers& wb, uint32_t w, uint32_t h, uint32_t first_sample,
+                          uint32_t samples_in_batch, hipStream_t s);
 void launch_extend(const DeviceScene& sc, const float4* ray_o, const float4* ray_d, uint32_t stride, float4* hits, const uint32_t* count,
-                   uint32_t* work_cursor, unsigned long long* stats, bool count_traversal, bool any_hit, const LaunchCfg& cfg, hipStream_t s);
+                   uint32_t* work_cursor, unsigned long long* stats, bool count_traversal, bool any_hit, const LaunchCfg& cfg, hipStream_t s,
+                   const float4* primary_gen = nullptr);
 // AO pipeline (Ao.hlsl): classify primaries, spawn 16 rays per primary hit into ao_o/ao_d, count occluded rays into st_L
 void launch_ao_primary(const PtRtConsts& c, const WavefrontBuffers& wb, uint64_t n_paths, const LaunchCfg& cfg, hipStream_t s);
 void launch_ao_rays(const PtRtConsts& c, const DeviceScene& sc, const WavefrontBuffers& wb, float4* ao_o, float4* ao_d, uint32_t w, uint32_t h,
@@ -91,7 +95,7 @@ void launch_ao_rays(const PtRtConsts& c, const DeviceScene& sc, const WavefrontB
 void launch_ao_count(const WavefrontBuffers& wb, const float4* ao_hits, uint64_t n_paths, const LaunchCfg& cfg, hipStream_t s);
 void launch_hit_flags(const float4* hits, uint64_t n, uint8_t* flags, hipStream_t s);
 void launch_shade(const PtRtConsts& c, const DeviceScene& sc, const WavefrontBuffers& wb, int bounce, uint32_t w, uint32_t h,
-                  uint32_t first_sample, uint64_t max_paths, bool russian_roulette, const LaunchCfg& cfg, hipStream_t s);
+                  uint32_t first_sample, uint64_t max_paths, bool russian_roulette, const LaunchCfg& cfg, hipStream_t s, bool fused_primary = false);
 void launch_skyview_lut(const PtRtConsts& c, const uint2* tlut, float4* out, hipStream_t s);   // out: PT_SKYVIEW_TEXELS float4
 void launch_sky(const PtRtConsts& c, const uint2* lut, const float4* skyview, const WavefrontBuffers& wb, uint64_t max_paths, const LaunchCfg& cfg, hipStream_t s);
 void launch_resolve(const WavefrontBuffers& wb, float4* accum, uint32_t w, uint32_t h, uint32_t samples_in_batch, uint32_t num_bounces,

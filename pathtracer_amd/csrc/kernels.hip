@@ -94,27 +94,29 @@ __global__ void __launch_bounds__(256) k_generate(PtRtConsts c, float4* __restri
   const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p == 0) counters[CTR_AT(CTR_QCOUNT0)] = n_paths;
   if (p >= n_paths) return;
-  const uint32_t wh = w * h;
-  uint32_t pix, si, px, py;
-  FastDiv(wh, n_paths).divmod(p, si, pix);
-  FastDiv(w, wh).divmod(pix, py, px);
-  Rng rng = InitRNG(px, py, first_sample + si);
-  // PathTracing.hlsl:47-51 with the Q1 deviation: position = uPixel + jitter, jitter in [0,1)^2
-  v2 pixel;
-  pixel.x = (float)px;
-  pixel.y = (float)py;
-  const float jx = GetRand01(rng);
-  const float jy = GetRand01(rng);
-  pixel.x += jx;
-  pixel.y += jy;
-  pixel.x = clampf(pixel.x, 0.0f, (float)w);
-  pixel.y = clampf(pixel.y, 0.0f, (float)h);
+  PrimaryFrame f;
+  f.corner = ld3(c.myNearPlaneCorner); f.xAxis = ld3(c.myXAxis); f.yAxis = ld3(c.myYAxis); f.camPos = ld3(c.myCameraPos);
+  f.w = w; f.h = h; f.wh = w * h; f.first_sample = first_sample;
   v3 o, d;
-  GetPrimaryRay(pixel, w, h, ld3(c.myNearPlaneCorner), ld3(c.myXAxis), ld3(c.myYAxis), ld3(c.myCameraPos), o, d);
+  const uint32_t rng_w = PrimaryRayOfPath(p, f, o, d);
   ray_o[p] = make_float4(o.x, o.y, o.z, 0.0f);       // TMin 0.0   (:59)
   ray_d[p] = make_float4(d.x, d.y, d.z, 10000.0f);   // TMax 10000 (:61)
-  st_T[p] = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(rng.w));
+  st_T[p] = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(rng_w));
   st_L[p] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+}
+
+// Fused primaries (PT_OPT_FUSED_PRIMARY, default): no k_generate pass. k_extend computes a primary ray when it fetches
+// path p, bounce 0 of k_shade computes it again, and the path state starts as constants (T = 1, L = 0, two draws taken)
+// instead of being written and read back: 64 B written + 96 B read per path less. This kernel leaves the frame for
+// k_extend (4 x float4: corner|w, xAxis|h, yAxis|w*h, camPos|first_sample) and the queue count.
+__global__ void k_primary_setup(PtRtConsts c, float4* __restrict__ gen, uint32_t* __restrict__ counters, uint32_t w, uint32_t h,
+                                uint32_t first_sample, uint32_t n_paths) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  gen[0] = make_float4(c.myNearPlaneCorner[0], c.myNearPlaneCorner[1], c.myNearPlaneCorner[2], __uint_as_float(w));
+  gen[1] = make_float4(c.myXAxis[0], c.myXAxis[1], c.myXAxis[2], __uint_as_float(h));
+  gen[2] = make_float4(c.myYAxis[0], c.myYAxis[1], c.myYAxis[2], __uint_as_float(w * h));
+  gen[3] = make_float4(c.myCameraPos[0], c.myCameraPos[1], c.myCameraPos[2], __uint_as_float(first_sample));
+  counters[CTR_AT(CTR_QCOUNT0)] = n_paths;
 }
 
 // ------------------------------------------------------------------------------------------------ extend
@@ -135,7 +137,9 @@ __global__ void __launch_bounds__(256) k_extend(const uint4* __restrict__ nodes,
                                                 float4* __restrict__ hits, const uint32_t* __restrict__ count_ptr,
                                                 uint32_t* __restrict__ work_cursor, unsigned long long* __restrict__ stats,
                                                 uint32_t lds_entries, uint32_t spill_entries, uint2* __restrict__ spill, uint32_t stride, uint32_t fetch_min,
-                                                uint32_t postpone_pct, uint32_t dq_entries, uint32_t any_hit, float scene_mag, uint32_t top_nodes, uint32_t continue_pct) {
+                                                uint32_t postpone_pct, uint32_t dq_entries, uint32_t any_hit, float scene_mag, uint32_t top_nodes, uint32_t continue_pct,
+                                                const float4* __restrict__ gen) {
+  // gen != nullptr: the queue is the batch's primary rays, computed here from the path index (k_primary_setup)
   // any_hit (wave-uniform): a ray ends at the first accepted intersection (occlusion queries: Ao.hlsl's ClosestHitAo
   // only reports that something was hit). Only "prim != miss" is then defined in the hit record.
   extern __shared__ uint2 s_stack[];
@@ -202,10 +206,21 @@ __global__ void __launch_bounds__(256) k_extend(const uint4* __restrict__ nodes,
         const uint32_t rank = (uint32_t)__popcll(idle_mask & ((1ull << lane) - 1ull));
         if (!busy && rank < take) {
           ray_i = pool_next + rank;
-          const float4 ro = ray_o[(size_t)ray_i * stride], rd = ray_d[(size_t)ray_i * stride];
           TraceRay r;
-          r.ox = ro.x; r.oy = ro.y; r.oz = ro.z; r.tmin = ro.w;
-          r.dx = rd.x; r.dy = rd.y; r.dz = rd.z; r.tmax = rd.w;
+          if (gen != nullptr) {
+            const float4 g0 = gen[0], g1 = gen[1], g2 = gen[2], g3 = gen[3];
+            PrimaryFrame f;
+            f.corner = mk3(g0.x, g0.y, g0.z); f.xAxis = mk3(g1.x, g1.y, g1.z); f.yAxis = mk3(g2.x, g2.y, g2.z); f.camPos = mk3(g3.x, g3.y, g3.z);
+            f.w = __float_as_uint(g0.w); f.h = __float_as_uint(g1.w); f.wh = __float_as_uint(g2.w); f.first_sample = __float_as_uint(g3.w);
+            v3 o, d;
+            (void)PrimaryRayOfPath(ray_i, f, o, d);
+            r.ox = o.x; r.oy = o.y; r.oz = o.z; r.tmin = 0.0f;          // TMin 0.0, TMax 10000 (PathTracing.hlsl:59-61)
+            r.dx = d.x; r.dy = d.y; r.dz = d.z; r.tmax = 10000.0f;
+          } else {
+            const float4 ro = ray_o[(size_t)ray_i * stride], rd = ray_d[(size_t)ray_i * stride];
+            r.ox = ro.x; r.oy = ro.y; r.oz = ro.z; r.tmin = ro.w;
+            r.dx = rd.x; r.dy = rd.y; r.dz = rd.z; r.tmax = rd.w;
+          }
           // A ray with a NaN/Inf component can hit nothing (every comparison of the triangle test fails), but fmin/fmax
           // drop NaNs, so its box tests would all pass and it would walk the whole BVH: report the miss right away.
           const float chk = (r.ox + r.oy + r.oz) + (r.dx + r.dy + r.dz);
@@ -319,7 +334,7 @@ __global__ void __launch_bounds__(256) k_extend(const uint4* __restrict__ nodes,
 #ifndef PT_SHADE_MIN_WAVES
 #define PT_SHADE_MIN_WAVES 1
 #endif
-template <bool EXT>
+template <bool EXT, bool FUSED>
 __global__ void __launch_bounds__(PT_SHADE_THREADS, PT_SHADE_MIN_WAVES) k_shade(PtRtConsts c, DeviceScene sc, const float4* __restrict__ ray_o_in,
                                                const float4* __restrict__ ray_d_in, const uint32_t* __restrict__ qid_in,
                                                const float4* __restrict__ hits, float4* __restrict__ st_T,
@@ -328,6 +343,8 @@ __global__ void __launch_bounds__(PT_SHADE_THREADS, PT_SHADE_MIN_WAVES) k_shade(
                                                float4* __restrict__ sky_o, float4* __restrict__ sky_d,
                                                uint32_t* __restrict__ counters, int bounce, uint32_t w, uint32_t h,
                                                uint32_t first_sample, uint32_t russian_roulette) {
+  // FUSED (only at bounce 0): no k_generate ran; the ray is recomputed from the path index, T = 1, L = 0 and the
+  // RNG counter after the jitter are constants, and this kernel (k_sky for sky misses) gives st_L its first value
   const uint32_t n = counters[CTR_AT(CTR_QCOUNT0 + bounce)];
   __shared__ BlockAppendLds s_app;
   const uint32_t lane = threadIdx.x & 63u;
@@ -335,6 +352,9 @@ __global__ void __launch_bounds__(PT_SHADE_THREADS, PT_SHADE_MIN_WAVES) k_shade(
   const uint32_t wh = w * h;
   uint32_t shaded_local = 0u, miss_local = 0u;
   const FastDiv div_wh(wh, 0x7fffffffu), div_w(w, wh);   // path ids stay below 2^31 (pt_api.cpp batch sizing)
+  PrimaryFrame pf;
+  pf.corner = ld3(c.myNearPlaneCorner); pf.xAxis = ld3(c.myXAxis); pf.yAxis = ld3(c.myYAxis); pf.camPos = ld3(c.myCameraPos);
+  pf.w = w; pf.h = h; pf.wh = wh; pf.first_sample = first_sample;
   int parity = 0;
   for (uint32_t j0 = blockIdx.x * blockDim.x; j0 < n; j0 += gridDim.x * blockDim.x, parity ^= 1) {  // block-uniform trip count
     const uint32_t j = j0 + threadIdx.x;
@@ -344,15 +364,23 @@ __global__ void __launch_bounds__(PT_SHADE_THREADS, PT_SHADE_MIN_WAVES) k_shade(
     v3 origin = mk3(0.0f), dir = mk3(0.0f), newOrigin = mk3(0.0f), newDir = mk3(0.0f);
     if (active) {
       pid = qid_in ? qid_in[j] : j;
-      const float4 ro = ray_o_in[j], rd = ray_d_in[j], hr = hits[j];
-      origin = mk3(ro.x, ro.y, ro.z);
-      dir = mk3(rd.x, rd.y, rd.z);
+      const float4 hr = hits[j];
+      if (FUSED) {
+        (void)PrimaryRayOfPath(j, pf, origin, dir);
+      } else {
+        const float4 ro = ray_o_in[j], rd = ray_d_in[j];
+        origin = mk3(ro.x, ro.y, ro.z);
+        dir = mk3(rd.x, rd.y, rd.z);
+      }
       const uint32_t prim = __float_as_uint(hr.w);
       if (prim == 0xFFFFFFFFu) {
         // miss: PathTracing.hlsl:73-77
         ++miss_local;
         if (c.mySampleSky) {
           want_sky = true;
+        } else if (FUSED) {   // T = 1, L = 0
+          const v3 add = mk3(1.0f) * ld3(c.mySkyFallbackEmission);
+          st_L[pid] = make_float4(0.0f + add.x, 0.0f + add.y, 0.0f + add.z, 0.0f);
         } else {
           const float4 T = st_T[pid];
           float4 L = st_L[pid];
@@ -395,7 +423,9 @@ __global__ void __launch_bounds__(PT_SHADE_THREADS, PT_SHADE_MIN_WAVES) k_shade(
         if (instanceId == c.myLightInstanceId) emission = ld3(c.myLightEmission);
 
         // ---- RayGen loop body: PathTracing.hlsl:83-127 ----
-        float4 Ts = st_T[pid];
+        float4 Ts;
+        if (FUSED) Ts = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(2u));   // two jitter draws taken (Random.hlsl:96-99)
+        else Ts = st_T[pid];
         v3 transmission = mk3(Ts.x, Ts.y, Ts.z);
         Rng rng;
         uint32_t pix, si;
@@ -433,7 +463,9 @@ __global__ void __launch_bounds__(PT_SHADE_THREADS, PT_SHADE_MIN_WAVES) k_shade(
         }
         }
         const v3 add = alive ? transmission * emission : mk3(0.0f);   // :108 — after the throughput update (Q3)
-        if (!(add.x == 0.0f && add.y == 0.0f && add.z == 0.0f)) {   // L + 0 == L: skip the RMW (a NaN term still lands, Q7)
+        if (FUSED) {
+          st_L[pid] = make_float4(0.0f + add.x, 0.0f + add.y, 0.0f + add.z, 0.0f);   // first value of L
+        } else if (!(add.x == 0.0f && add.y == 0.0f && add.z == 0.0f)) {   // L + 0 == L: skip the RMW (a NaN term still lands, Q7)
           float4 Ls = st_L[pid];
           Ls.x += add.x; Ls.y += add.y; Ls.z += add.z;
           st_L[pid] = Ls;
@@ -462,7 +494,7 @@ __global__ void __launch_bounds__(PT_SHADE_THREADS, PT_SHADE_MIN_WAVES) k_shade(
     }
     if (want_sky) {
       sky_o[sslot] = make_float4(origin.x, origin.y, origin.z, __uint_as_float(pid));
-      sky_d[sslot] = make_float4(dir.x, dir.y, dir.z, 0.0f);
+      sky_d[sslot] = make_float4(dir.x, dir.y, dir.z, FUSED ? 1.0f : 0.0f);   // w != 0: T = 1 and L = 0, not in memory
     }
   }
   // one atomic per wave for the statistics
@@ -497,8 +529,14 @@ __global__ void __launch_bounds__(256) k_sky(PtRtConsts c, const uint2* __restri
     v3 sky;
     if (VIEW_LUT) sky = SampleSkyLuminanceViewLut(mk3(o.x, o.y, o.z), mk3(d.x, d.y, d.z), c, skyview, frame);
     else sky = SampleSkyLuminance(mk3(o.x, o.y, o.z), mk3(d.x, d.y, d.z), c, lut);
-    const float4 T = st_T[pid];
-    float4 L = st_L[pid];
+    float4 T, L;
+    if (d.w != 0.0f) {   // a primary that missed under PT_OPT_FUSED_PRIMARY: its state is still the initial constants
+      T = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
+      L = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    } else {
+      T = st_T[pid];
+      L = st_L[pid];
+    }
     const v3 add = mk3(T.x, T.y, T.z) * sky;
     L.x += add.x; L.y += add.y; L.z += add.z;
     st_L[pid] = L;
@@ -733,6 +771,11 @@ void launch_generate(const PtRtConsts& c, const WavefrontBuffers& wb, uint32_t w
                      wb.counters, w, h, first_sample, n);
 }
 
+void launch_primary_setup(const PtRtConsts& c, const WavefrontBuffers& wb, uint32_t w, uint32_t h, uint32_t first_sample,
+                          uint32_t samples_in_batch, hipStream_t s) {
+  hipLaunchKernelGGL(k_primary_setup, dim3(1), dim3(64), 0, s, c, wb.gen, wb.counters, w, h, first_sample, w * h * samples_in_batch);
+}
+
 size_t extend_lds_bytes(uint32_t lds_entries_total, uint32_t top_nodes) {
   return (size_t)lds_entries_total * 64u * sizeof(uint2) * 4u + (size_t)top_nodes * PT_NODE_STRIDE_U4 * 16u;
 }
@@ -750,7 +793,8 @@ int extend_occupancy_blocks(uint32_t lds_entries_total, uint32_t top_nodes, bool
 }
 
 void launch_extend(const DeviceScene& sc, const float4* ray_o, const float4* ray_d, uint32_t stride, float4* hits, const uint32_t* count,
-                   uint32_t* work_cursor, unsigned long long* stats, bool count_traversal, bool any_hit, const LaunchCfg& cfg, hipStream_t s) {
+                   uint32_t* work_cursor, unsigned long long* stats, bool count_traversal, bool any_hit, const LaunchCfg& cfg, hipStream_t s,
+                   const float4* primary_gen) {
   uint32_t lds_entries = sc.stack_entries < cfg.lds_stack_entries ? sc.stack_entries : cfg.lds_stack_entries;
   if (lds_entries + cfg.defer_entries > PT_EXTEND_MAX_LDS_ENTRIES)   // 2 KB of LDS per entry and block: stay within one CU's LDS
     lds_entries = PT_EXTEND_MAX_LDS_ENTRIES - cfg.defer_entries;     // the rest of the stack goes to the spill region
@@ -768,7 +812,7 @@ void launch_extend(const DeviceScene& sc, const float4* ray_o, const float4* ray
   }
 #define PT_LAUNCH_EXTEND(C, D, P)                                                                                           \
   hipLaunchKernelGGL((k_extend<C, D, P>), dim3(cfg.extend_blocks), dim3(256), lds, s, sc.nodes, sc.tris, ray_o, ray_d, hits, count, \
-                     work_cursor, stats, lds_entries, spill_entries, sc.spill, stride, cfg.fetch_min, cfg.postpone_pct, dq, any_hit ? 1u : 0u, sc.scene_mag, top_nodes, cfg.continue_pct)
+                     work_cursor, stats, lds_entries, spill_entries, sc.spill, stride, cfg.fetch_min, cfg.postpone_pct, dq, any_hit ? 1u : 0u, sc.scene_mag, top_nodes, cfg.continue_pct, primary_gen)
 #define PT_LAUNCH_EXTEND2(C, D) do { if (sc.paired) PT_LAUNCH_EXTEND(C, D, true); else PT_LAUNCH_EXTEND(C, D, false); } while (0)
   if (dq > 0) {
     if (count_traversal) PT_LAUNCH_EXTEND2(true, true); else PT_LAUNCH_EXTEND2(false, true);
@@ -780,17 +824,21 @@ void launch_extend(const DeviceScene& sc, const float4* ray_o, const float4* ray
 }
 
 void launch_shade(const PtRtConsts& c, const DeviceScene& sc, const WavefrontBuffers& wb, int bounce, uint32_t w, uint32_t h,
-                  uint32_t first_sample, uint64_t max_paths, bool russian_roulette, const LaunchCfg& cfg, hipStream_t s) {
+                  uint32_t first_sample, uint64_t max_paths, bool russian_roulette, const LaunchCfg& cfg, hipStream_t s, bool fused_primary) {
   const int in = bounce & 1, out = in ^ 1;
   uint64_t g = (max_paths + PT_SHADE_THREADS - 1) / PT_SHADE_THREADS;
   const uint64_t cap = (uint64_t)cfg.num_cus * 8u;
   if (g > cap) g = cap;
   if (g < 1) g = 1;
-#define PT_LAUNCH_SHADE(E)                                                                                                  \
-  hipLaunchKernelGGL(k_shade<E>, dim3((unsigned)g), dim3(PT_SHADE_THREADS), 0, s, c, sc, wb.ray_o[in], wb.ray_d[in],        \
+#define PT_LAUNCH_SHADE(E, F)                                                                                               \
+  hipLaunchKernelGGL((k_shade<E, F>), dim3((unsigned)g), dim3(PT_SHADE_THREADS), 0, s, c, sc, wb.ray_o[in], wb.ray_d[in],   \
                      bounce == 0 ? (const uint32_t*)nullptr : wb.qid[in], wb.hits, wb.st_T, wb.st_L, wb.ray_o[out], wb.ray_d[out], \
                      wb.qid[out], wb.sky_o, wb.sky_d, wb.counters, bounce, w, h, first_sample, russian_roulette ? 1u : 0u)
-  if (sc.instance_ext) PT_LAUNCH_SHADE(true); else PT_LAUNCH_SHADE(false);
+  if (fused_primary && bounce == 0) {
+    if (sc.instance_ext) PT_LAUNCH_SHADE(true, true); else PT_LAUNCH_SHADE(false, true);
+  } else {
+    if (sc.instance_ext) PT_LAUNCH_SHADE(true, false); else PT_LAUNCH_SHADE(false, false);
+  }
 #undef PT_LAUNCH_SHADE
 }
 

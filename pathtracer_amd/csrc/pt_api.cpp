@@ -24,6 +24,10 @@ using namespace pt;
 
 static thread_local std::string g_create_error;
 
+#ifndef PT_DEFAULT_FUSED_PRIMARY
+#define PT_DEFAULT_FUSED_PRIMARY 1   // A/B builds: -DPT_DEFAULT_FUSED_PRIMARY=0
+#endif
+
 struct pt_ctx {
   int device = 0;
   hipStream_t own_stream = nullptr;
@@ -63,6 +67,8 @@ struct pt_ctx {
   hipStream_t stream2 = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   bool pipeline = false;
+  bool fused_primary = PT_DEFAULT_FUSED_PRIMARY != 0;   // PT_OPT_FUSED_PRIMARY
+  bool last_render_fused = false;     // the bounce-0 queue of the last pt_render was never written (pt_debug_read_queue)
   float4* ao_o = nullptr;       // AO pipeline: 16 rays per pixel-sample (origin,tmin / dir,tmax / hit records)
   float4* ao_d = nullptr;
   float4* ao_hits = nullptr;
@@ -180,6 +186,7 @@ int ensure_wavefront_for(pt_ctx* ctx, WavefrontBuffers& wb, std::vector<void*>& 
   if ((rc = dev_alloc(ctx, &wb.st_L, paths, &allocs))) return rc;
   if ((rc = dev_alloc(ctx, &wb.sky_o, paths, &allocs))) return rc;
   if ((rc = dev_alloc(ctx, &wb.sky_d, paths, &allocs))) return rc;
+  if ((rc = dev_alloc(ctx, &wb.gen, (size_t)4, &allocs))) return rc;
   if ((rc = dev_alloc(ctx, &wb.counters, (size_t)CTR_WORDS, &allocs))) return rc;
   if (!wb.stats) {
     if ((rc = dev_alloc(ctx, &wb.stats, (size_t)ST_WORDS, &allocs))) return rc;
@@ -255,7 +262,7 @@ int check_consts(pt_ctx* ctx, const PtRtConsts* c, bool need_sky) {
 }
 
 void extend_one(pt_ctx* ctx, const float4* ro, const float4* rd, uint32_t stride, float4* hits, const uint32_t* count, uint32_t* cursor, int bounce = 0,
-                bool any_hit = false, int lane = 0) {
+                bool any_hit = false, int lane = 0, const float4* primary_gen = nullptr) {
   const hipStream_t st = lane ? ctx->stream2 : ctx->stream;
   std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
   if (ctx->time_kernels) {
@@ -265,9 +272,9 @@ void extend_one(pt_ctx* ctx, const float4* ro, const float4* rd, uint32_t stride
   if (lane) {
     DeviceScene ds2 = ctx->ds;
     ds2.spill = ctx->spill2;
-    launch_extend(ds2, ro, rd, stride, hits, count, cursor, ctx->wb2.stats, ctx->count_traversal, any_hit, ctx->cfg, st);
+    launch_extend(ds2, ro, rd, stride, hits, count, cursor, ctx->wb2.stats, ctx->count_traversal, any_hit, ctx->cfg, st, primary_gen);
   } else {
-    launch_extend(ctx->ds, ro, rd, stride, hits, count, cursor, ctx->wb.stats, ctx->count_traversal, any_hit, ctx->cfg, st);
+    launch_extend(ctx->ds, ro, rd, stride, hits, count, cursor, ctx->wb.stats, ctx->count_traversal, any_hit, ctx->cfg, st, primary_gen);
   }
   ctx->extend_launches++;
   if (ctx->time_kernels) {
@@ -394,6 +401,10 @@ int pt_set_option(pt_ctx* ctx, int option, int64_t value) {
       ctx->cfg.defer_entries = (uint32_t)value;
       if (ctx->has_scene)
         ctx->cfg.extend_blocks = extend_grid(ctx);
+      return PT_OK;
+    case PT_OPT_FUSED_PRIMARY:
+      if (value != 0 && value != 1) return ctx->fail(PT_ERR_INVALID_ARG, "PT_OPT_FUSED_PRIMARY must be 0 or 1");
+      ctx->fused_primary = value != 0;
       return PT_OK;
     case PT_OPT_EXTEND_CONTINUE_PCT:
       if (value < 0 || value > 100) return ctx->fail(PT_ERR_INVALID_ARG, "continue_pct must be 0..100");
@@ -714,6 +725,8 @@ int pt_render(pt_ctx* ctx, const PtRtConsts* consts, uint32_t width, uint32_t he
   const uint32_t bounces = consts->myMaxRecursionDepth + 1;  // inclusive loop bound (PathTracing.hlsl:68)
   const bool use_skyview = ctx->sky_mode == 1 && consts->mySampleSky && skyview_valid_for(*consts);
   if (use_skyview) launch_skyview_lut(*consts, ctx->lut, ctx->skyview, ctx->stream);   // 64 Ki texels, a few microseconds
+  const bool fused = ctx->fused_primary;   // primaries computed inside k_extend / k_shade instead of a k_generate pass
+  ctx->last_render_fused = fused;
   for (uint32_t done = 0; done < num_samples;) {
     const uint32_t k = (uint32_t)std::min<uint64_t>(spb, num_samples - done);
     const uint32_t k_lane[2] = {two_lanes && k >= 2 ? (k + 1) / 2 : k, two_lanes && k >= 2 ? k / 2 : 0};
@@ -727,14 +740,16 @@ int pt_render(pt_ctx* ctx, const PtRtConsts* consts, uint32_t width, uint32_t he
     }
     for (int l = 0; l < n_lanes; ++l) {
       PT_HIP(hipMemsetAsync(wbs[l]->counters, 0, CTR_WORDS * sizeof(uint32_t), streams[l]));
-      launch_generate(*consts, *wbs[l], width, height, first_lane[l], k_lane[l], streams[l]);
+      if (fused) launch_primary_setup(*consts, *wbs[l], width, height, first_lane[l], k_lane[l], streams[l]);
+      else launch_generate(*consts, *wbs[l], width, height, first_lane[l], k_lane[l], streams[l]);
     }
     for (uint32_t b = 0; b < bounces; ++b) {
       const int in = (int)(b & 1u);
       for (int l = 0; l < n_lanes; ++l) {
         WavefrontBuffers& wb = *wbs[l];
-        extend_one(ctx, wb.ray_o[in], wb.ray_d[in], 1, wb.hits, wb.counters + CTR_AT(CTR_QCOUNT0 + b), wb.counters + CTR_AT(CTR_WORK0 + b), (int)b, false, l);
-        launch_shade(*consts, ctx->ds, wb, (int)b, width, height, first_lane[l], wh * k_lane[l], ctx->russian_roulette, ctx->cfg, streams[l]);
+        extend_one(ctx, wb.ray_o[in], wb.ray_d[in], 1, wb.hits, wb.counters + CTR_AT(CTR_QCOUNT0 + b), wb.counters + CTR_AT(CTR_WORK0 + b), (int)b, false, l,
+                   (fused && b == 0) ? wb.gen : nullptr);
+        launch_shade(*consts, ctx->ds, wb, (int)b, width, height, first_lane[l], wh * k_lane[l], ctx->russian_roulette, ctx->cfg, streams[l], fused);
       }
     }
     for (int l = 0; l < n_lanes; ++l)
@@ -779,6 +794,7 @@ int pt_render_ao(pt_ctx* ctx, const PtRtConsts* consts, uint32_t width, uint32_t
   for (uint32_t s = 0; s < num_samples; ++s) {   // one reference frame (1 primary + <=16 AO rays per pixel) per batch
     PT_HIP(hipMemsetAsync(ctx->wb.counters, 0, CTR_WORDS * sizeof(uint32_t), ctx->stream));
     launch_generate(*consts, ctx->wb, width, height, first_sample + s, 1, ctx->stream);
+    ctx->last_render_fused = false;
     extend_one(ctx, ctx->wb.ray_o[0], ctx->wb.ray_d[0], 1, ctx->wb.hits, ctx->wb.counters + CTR_AT(CTR_QCOUNT0), ctx->wb.counters + CTR_AT(CTR_WORK0), 0);
     launch_ao_primary(*consts, ctx->wb, wh, ctx->cfg, ctx->stream);
     launch_ao_rays(*consts, ctx->ds, ctx->wb, ctx->ao_o, ctx->ao_d, width, height, first_sample + s, wh, ctx->cfg, ctx->stream);
@@ -841,6 +857,7 @@ int pt_primary_hits(pt_ctx* ctx, const PtRtConsts* consts, uint32_t width, uint3
   if ((rc = ensure_wavefront(ctx, wh)) != PT_OK) return rc;
   PT_HIP(hipMemsetAsync(ctx->wb.counters, 0, CTR_WORDS * sizeof(uint32_t), ctx->stream));
   launch_generate(*consts, ctx->wb, width, height, sample, 1, ctx->stream);
+  ctx->last_render_fused = false;
   extend_one(ctx, ctx->wb.ray_o[0], ctx->wb.ray_d[0], 1, ctx->wb.hits, ctx->wb.counters + CTR_AT(CTR_QCOUNT0), ctx->wb.counters + CTR_AT(CTR_WORK0));
   PT_HIP(hipGetLastError());
   PT_HIP(hipMemcpyAsync(hits, ctx->wb.hits, wh * sizeof(PtHit), hipMemcpyDeviceToHost, ctx->stream));
@@ -962,6 +979,8 @@ int pt_debug_eval(pt_ctx* ctx, int fn, const PtRtConsts* consts, const float* in
 int pt_debug_read_queue(pt_ctx* ctx, uint32_t bounce, PtRay* host_rays, uint64_t capacity, uint64_t* count_out) {
   PT_REQUIRE_CTX();
   if (!ctx->wb.counters || !count_out || bounce > 62) return ctx->fail(PT_ERR_INVALID_ARG, "no wavefront state or bad arguments");
+  if (bounce == 0 && ctx->last_render_fused)
+    return ctx->fail(PT_ERR_UNSUPPORTED, "the bounce-0 queue is not materialised under PT_OPT_FUSED_PRIMARY (set it to 0 before pt_render)");
   PT_HIP(hipStreamSynchronize(ctx->stream));
   uint32_t n = 0;
   PT_HIP(hipMemcpy(&n, ctx->wb.counters + CTR_AT(CTR_QCOUNT0 + bounce), sizeof(n), hipMemcpyDeviceToHost));

@@ -45,6 +45,27 @@ __device__ __forceinline__ void GetPrimaryRay(v2 pixel, uint32_t resX, uint32_t 
   origin = corner + xAxis * vx + yAxis * vy;
   dir = normalize(origin - camPos);
 }
+// RayGen's ray set-up for path sample p of a batch (PathTracing.hlsl:40-61 with the Q1 deviation: position = uPixel +
+// jitter). One function for k_generate, the fused fetch of k_extend and bounce 0 of k_shade, so all three produce the
+// same bits. p = sample_in_batch * w*h + y*w + x; returns the RNG draw counter after the two jitter draws.
+struct PrimaryFrame { v3 corner, xAxis, yAxis, camPos; uint32_t w, h, wh, first_sample; };
+__device__ __forceinline__ uint32_t PrimaryRayOfPath(uint32_t p, const PrimaryFrame& f, v3& origin, v3& dir) {
+  uint32_t pix, si, px, py;
+  FastDiv(f.wh, 0x7fffffffu).divmod(p, si, pix);     // path ids stay below 2^31 (pt_api.cpp batch sizing)
+  FastDiv(f.w, f.wh).divmod(pix, py, px);
+  Rng rng = InitRNG(px, py, f.first_sample + si);
+  v2 pixel;
+  pixel.x = (float)px;
+  pixel.y = (float)py;
+  const float jx = GetRand01(rng);
+  const float jy = GetRand01(rng);
+  pixel.x += jx;
+  pixel.y += jy;
+  pixel.x = clampf(pixel.x, 0.0f, (float)f.w);
+  pixel.y = clampf(pixel.y, 0.0f, (float)f.h);
+  GetPrimaryRay(pixel, f.w, f.h, f.corner, f.xAxis, f.yAxis, f.camPos, origin, dir);
+  return rng.w;
+}
 // GetLuminance — Common.hlsl:191-194
 __device__ __forceinline__ float GetLuminance(v3 c) { return dot(c, mk3(0.2126f, 0.7152f, 0.0722f)); }
 // GetFresnelSchlick — Common.hlsl:196-201

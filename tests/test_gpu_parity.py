@@ -1060,6 +1060,47 @@ def test_full_size_properties_1080p(ctx, oracle):
     assert 2 < st.nodes_visited / st.rays < 200 and 0.5 < st.tris_tested / st.rays < 100
 
 
+# ---------------------------------------------------------------------------------------------- fused primaries
+@pytest.mark.parametrize("sky,ext", [(True, False), (False, False), (True, True)])
+def test_fused_primary_rays_are_bit_identical_to_the_generate_pass(ctx, oracle, sky, ext):
+    """PT_OPT_FUSED_PRIMARY (default): primaries are computed inside k_extend / k_shade and the path state starts as
+    constants instead of a k_generate pass through memory. Same RayGen arithmetic (PathTracing.hlsl:40-61) in all
+    three places, so target sums, ray counts and per-bounce queues must not change by a bit; both pipeline settings."""
+    sc = scenes.with_material_ext(scenes.atrium(1)) if ext else scenes.atrium(1)
+    ctx.scene_create(sc)
+    ctx.sky_set(oracle.earth_atmosphere())
+    w, h, spp = 200, 120, 5
+    c = lookat_consts(w, h, scenes.ATRIUM_CAM, depth=4)
+    if not sky:
+        c.mySampleSky = 0
+        api.fill3(c.mySkyFallbackEmission, (1.5, 1.0, 0.5))
+    out = {}
+    try:
+        for fused in (0, 1):
+            for pipe in (0, 1):
+                ctx.set_option(api.PT_OPT_FUSED_PRIMARY, fused)
+                ctx.set_option(api.PT_OPT_PIPELINE, pipe)
+                ctx.accum_reset(w, h)
+                ctx.stats_reset()
+                ctx.render(c, w, h, 3, spp)
+                st = ctx.stats()
+                out[(fused, pipe)] = (ctx.accum_read_sum()[0].copy(), (st.rays, st.shaded_hits, st.sky_misses, tuple(st.rays_bounce)))
+        ctx.set_option(api.PT_OPT_PIPELINE, 0)
+        ctx.accum_reset(w, h)
+        ctx.render(c, w, h, 3, spp)                        # one lane again: the whole batch sits in the first lane's queues
+        q1 = ctx.debug_read_queue(1)                       # later queues stay readable
+        assert len(q1) == out[(1, 0)][1][3][1]
+        with pytest.raises(Exception):
+            ctx.debug_read_queue(0)                        # ... the bounce-0 queue does not exist in fused mode
+    finally:
+        ctx.set_option(api.PT_OPT_FUSED_PRIMARY, 1)
+        ctx.set_option(api.PT_OPT_PIPELINE, 0)
+    ref = out[(0, 0)]
+    for k, v in out.items():
+        assert v[1] == ref[1], k
+        assert np.array_equal(v[0].view(np.uint32), ref[0].view(np.uint32)), k
+
+
 # ---------------------------------------------------------------------------------------------- API behaviour
 def test_default_batch_shrinks_when_device_memory_is_short():
     """The default wavefront batch is 2^27 paths (20 GB). When that much device memory is not free, pt_render halves the
