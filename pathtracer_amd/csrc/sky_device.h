@@ -27,6 +27,25 @@ struct Atmo {  // sky/Common.hlsl:7-43, same 112-byte layout as PtAtmosphere
 };
 static_assert(sizeof(Atmo) == sizeof(PtAtmosphere), "atmosphere layout");
 
+// The per-miss march (IntegrateSkyLuminance) takes exp and the divisions that come AFTER the sample heights are formed
+// from the hardware unit: v_exp_f32 on x*log2(e) and v_rcp_f32 (1 ulp each) instead of OCML's expf and the IEEE division
+// sequence — about a quarter of the march's instructions. Everything upstream of a height (ray/sphere hits, sample
+// positions, |P|) keeps the exact forms: at |P| = 6.36e6 m one fp32 ulp is half a metre, so a different rounding there
+// moves a density by up to 4e-4, while these change results by ~1e-7 (test_sky_function_matches_oracle: median < 1e-5
+// of the brightest channel). The transmittance-LUT build keeps expf (its halfs must match the oracle's).
+// -DPT_SKY_LIBM_FORMS=1 builds the exact forms back in.
+#ifndef PT_SKY_LIBM_FORMS
+#define PT_SKY_LIBM_FORMS 0
+#endif
+template <bool FAST>
+__device__ __forceinline__ float sky_exp(float x) {
+  return (FAST && !PT_SKY_LIBM_FORMS) ? __builtin_amdgcn_exp2f(x * 1.44269504088896340736f) : expf(x);
+}
+template <bool FAST>
+__device__ __forceinline__ float sky_div(float a, float b) {
+  return (FAST && !PT_SKY_LIBM_FORMS) ? a * __builtin_amdgcn_rcpf(b) : a / b;
+}
+
 // raySphereIntersectNearest — sky/Common.hlsl:75-101
 __device__ __forceinline__ float raySphereIntersectNearest(v3 r0, v3 rd, v3 s0, float sR) {
   float a = dot(rd, rd);
@@ -45,6 +64,7 @@ __device__ __forceinline__ float raySphereIntersectNearest(v3 r0, v3 rd, v3 s0, 
 }
 
 // LutTransmittanceParamsToUv — sky/Common.hlsl:103-117
+template <bool FAST>
 __device__ __forceinline__ v2 LutTransmittanceParamsToUv(float bottomR, float topR, float viewHeight, float mu) {
   float H = sqrtf(fmaxf(0.0f, topR * topR - bottomR * bottomR));
   float rho = sqrtf(fmaxf(0.0f, viewHeight * viewHeight - bottomR * bottomR));
@@ -53,8 +73,8 @@ __device__ __forceinline__ v2 LutTransmittanceParamsToUv(float bottomR, float to
   float d_min = topR - viewHeight;
   float d_max = rho + H;
   v2 uv;
-  uv.x = (d - d_min) / (d_max - d_min);
-  uv.y = rho / H;
+  uv.x = sky_div<FAST>(d - d_min, d_max - d_min);
+  uv.y = sky_div<FAST>(rho, H);
   return uv;
 }
 
@@ -73,10 +93,11 @@ __device__ __forceinline__ void UvToLutTransmittanceParams(const Atmo& A, float&
 
 struct Medium { v3 scattering, extinction, scatteringMie, scatteringRay; };
 // sampleMediumRGB — sky/Common.hlsl:191-221
+template <bool FAST>
 __device__ __forceinline__ Medium sampleMediumRGB(v3 P, const Atmo& A) {
   const float viewHeight = length(P) - A.BottomRadius;
-  const float densityMie = expf(A.MieDensityExpScale * viewHeight);
-  const float densityRay = expf(A.RayleighDensityExpScale * viewHeight);
+  const float densityMie = sky_exp<FAST>(A.MieDensityExpScale * viewHeight);
+  const float densityRay = sky_exp<FAST>(A.RayleighDensityExpScale * viewHeight);
   const float densityOzo = saturate(viewHeight < A.AbsorptionDensity0LayerWidth
                                         ? A.AbsorptionDensity0LinearTerm * viewHeight + A.AbsorptionDensity0ConstantTerm
                                         : A.AbsorptionDensity1LinearTerm * viewHeight + A.AbsorptionDensity1ConstantTerm);
@@ -196,7 +217,7 @@ __device__ __forceinline__ v3 IntegrateOpticalDepth(v3 P0, v3 dir, const Atmo& A
     float dt = NewT - t;
     t = NewT;
     v3 P = P0 + t * dir;
-    Medium medium = sampleMediumRGB(P, A);
+    Medium medium = sampleMediumRGB<false>(P, A);
     v3 SampleOpticalDepth = medium.extinction * dt;
     OpticalDepth = OpticalDepth + SampleOpticalDepth;
   }
@@ -250,14 +271,14 @@ __device__ __forceinline__ v3 IntegrateSkyLuminance(v3 P0, v3 dir, v3 sunDir, co
     float dt = t1 - t0;
     v3 P = P0 + t * dir;
 
-    Medium medium = sampleMediumRGB(P, A);
+    Medium medium = sampleMediumRGB<true>(P, A);
     v3 SampleOpticalDepth = medium.extinction * dt;
-    v3 SampleTransmittance = exp3(-SampleOpticalDepth);
+    v3 SampleTransmittance = mk3(sky_exp<true>(-SampleOpticalDepth.x), sky_exp<true>(-SampleOpticalDepth.y), sky_exp<true>(-SampleOpticalDepth.z));
 
     float pHeight = length(P);
     v3 UpVector = P / pHeight;
     float SunZenithCosAngle = dot(sunDir, UpVector);
-    v2 uv = LutTransmittanceParamsToUv(A.BottomRadius, A.TopRadius, pHeight, SunZenithCosAngle);
+    v2 uv = LutTransmittanceParamsToUv<true>(A.BottomRadius, A.TopRadius, pHeight, SunZenithCosAngle);
     v3 TransmittanceToSun = SampleTransmittanceLut(lut, uv);
 
     v3 PhaseTimesScattering = medium.scatteringMie * MiePhaseValue + medium.scatteringRay * RayleighPhaseValue;
@@ -267,7 +288,8 @@ __device__ __forceinline__ v3 IntegrateSkyLuminance(v3 P0, v3 dir, v3 sunDir, co
     v3 multiScatteredLuminance = mk3(0.0f);
     float shadow = 1.0f;
     v3 S = globalL * (earthShadow * shadow * TransmittanceToSun * PhaseTimesScattering + multiScatteredLuminance * medium.scattering);
-    v3 Sint = (S - S * SampleTransmittance) / medium.extinction;
+    const v3 dS = S - S * SampleTransmittance;
+    v3 Sint = mk3(sky_div<true>(dS.x, medium.extinction.x), sky_div<true>(dS.y, medium.extinction.y), sky_div<true>(dS.z, medium.extinction.z));
     L = L + throughput * Sint;
     throughput = throughput * SampleTransmittance;
   }
