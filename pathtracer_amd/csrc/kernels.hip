@@ -226,6 +226,14 @@ __global__ void __launch_bounds__(256) k_extend(const uint4* __restrict__ nodes,
           const float chk = (r.ox + r.oy + r.oz) + (r.dx + r.dy + r.dz);
           if (isfinite(chk)) {
             tr.init(r, scene_mag);
+#ifdef PT_EXP_EXTRA_REFILL_VALU   // experiment: N more vector instructions per refilled ray: what does the refill path cost?
+            {
+              float d = r.ox;
+#pragma unroll
+              for (int k = 0; k < PT_EXP_EXTRA_REFILL_VALU; ++k) asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(d));
+              asm volatile("" ::"v"(d));
+            }
+#endif
             busy = true;
           } else {
             hits[ray_i] = make_float4(-1.0f, 0.0f, 0.0f, __uint_as_float(0xFFFFFFFFu));
