@@ -324,20 +324,38 @@ struct Traverser {
 #endif
 
     const uint32_t e = n0.w;
+#if PT_MIX_FMA
+    // 2^e * 2^24, built in the exponent field: byte -> (byte << 23) + (24 << 23), one v_lshl_add_u32 per axis (pinned as
+    // asm like the other shift-adds). e + 24 < 255 for every scene the fast form is used on: coordinates beyond 2^103 make
+    // every ray risky, and the safe form takes the bias off again.
+    uint32_t sx24u, sy24u, sz24u;
+    {
+      const uint32_t bias = 0x0C000000u, ex = e & 0xffu, ey = (e >> 8) & 0xffu, ez = (e >> 16) & 0xffu;
+      asm("v_lshl_add_u32 %0, %1, 23, %2" : "=v"(sx24u) : "v"(ex), "s"(bias));
+      asm("v_lshl_add_u32 %0, %1, 23, %2" : "=v"(sy24u) : "v"(ey), "s"(bias));
+      asm("v_lshl_add_u32 %0, %1, 23, %2" : "=v"(sz24u) : "v"(ez), "s"(bias));
+    }
+#else
     const float sx = __uint_as_float((e & 0xffu) << 23), sy = __uint_as_float(((e >> 8) & 0xffu) << 23),
                 sz = __uint_as_float(((e >> 16) & 0xffu) << 23);
+#endif
     const float px = __uint_as_float(n0.x) - ray.ox, py = __uint_as_float(n0.y) - ray.oy, pz = __uint_as_float(n0.z) - ray.oz;
-    const bool negx = (oct & 1u) != 0u, negy = (oct & 2u) != 0u, negz = (oct & 4u) != 0u;
+    // the octant bits, read off the reciprocal directions (same signs by construction in init: one compare each)
+    const bool negx = idx < 0.0f, negy = idy < 0.0f, negz = idz < 0.0f;
     uint32_t hitmask = 0u;
     // Fast form: t = q * (2^e / d) + (p - o) / d, one FMA per plane. Its two terms can overflow fp32 although their sum
     // is small (|scene coordinate| / |d| > ~1e37: astronomically large scenes, or near-axis-parallel rays in large
     // ones); such rays (flagged once, at init) take the safe form t = (q * 2^e + (p - o)) / d, where only a genuinely
     // huge distance overflows, with the right sign. The wave-level test keeps the safe form out of ordinary waves.
     if (wave_risky && risky) {
+#if PT_MIX_FMA
+      const float sx = __uint_as_float(sx24u - 0x0C000000u), sy = __uint_as_float(sy24u - 0x0C000000u), sz = __uint_as_float(sz24u - 0x0C000000u);
+#endif
       child_tests<true>(n1, n2, n3, n4, sx, sy, sz, px, py, pz, negx, negy, negz, oct4, hitmask);
     } else {
 #if PT_MIX_FMA
-      child_tests<false>(n1, n2, n3, n4, sx * idx * 16777216.0f, sy * idy * 16777216.0f, sz * idz * 16777216.0f, px * idx, py * idy, pz * idz, negx, negy, negz, oct4, hitmask);
+      child_tests<false>(n1, n2, n3, n4, __uint_as_float(sx24u) * idx, __uint_as_float(sy24u) * idy, __uint_as_float(sz24u) * idz, px * idx, py * idy, pz * idz,
+                         negx, negy, negz, oct4, hitmask);
 #else
       child_tests<false>(n1, n2, n3, n4, sx * idx, sy * idy, sz * idz, px * idx, py * idy, pz * idz, negx, negy, negz, oct4, hitmask);
 #endif
