@@ -30,7 +30,7 @@ NODE_FLOP, TRI_FLOP = 176.0, 45.0                  # F_ray = 8*22
 FP32_PEAK_TFLOPS = 157.3                           # MI355X_MICROARCH.md: peak fp32 vector
 L1_PEAK_GBS = 39321.6                              # vector L1 return path: 64 B/clk/CU x 256 CUs x 2.4 GHz
 PMC_ROUND = "r02"                                  # profiles/<round>/pmc_traffic.json: counters of THIS build
-DEF_DEFER, DEF_POSTPONE = 4, 50                   # the library defaults (csrc/kernels.h LaunchCfg)
+DEF_DEFER, DEF_POSTPONE = 4, 40                   # the library defaults (csrc/kernels.h LaunchCfg)
 
 
 def make_workload(name):

@@ -67,13 +67,19 @@ struct WavefrontBuffers {
 #define PT_SCRATCH_HEADER 512u
 hipError_t scratch_address(void** out);   // address of the CURRENT device's copy of the array
 
+#ifndef PT_DEF_POSTPONE_PCT
+#define PT_DEF_POSTPONE_PCT 40
+#endif
+#ifndef PT_DEF_CONTINUE_PCT
+#define PT_DEF_CONTINUE_PCT 25
+#endif
 struct LaunchCfg {
   int num_cus = 256;
   int extend_blocks = 1024;   // persistent grid of the extend kernel
   int stream_blocks = 2048;   // grid cap of the grid-stride kernels
   uint32_t fetch_min = 16;    // extend: refill idle lanes once this many of the 64 are idle
-  uint32_t postpone_pct = 50; // extend: postpone triangle tests while fewer than this % of busy lanes have any
-  uint32_t continue_pct = 25; // extend (deferred schedule): a triangle phase goes on while at least this % of busy lanes have work
+  uint32_t postpone_pct = PT_DEF_POSTPONE_PCT; // extend: postpone triangle tests while fewer than this % of busy lanes have any
+  uint32_t continue_pct = PT_DEF_CONTINUE_PCT; // extend (deferred schedule): a triangle phase goes on while at least this % of busy lanes have work
   int extend_blocks_per_cu = 0; // 0 = from the occupancy query
   uint32_t lds_stack_entries = 6; // per-lane stack entries kept in LDS; deeper entries spill to global memory
   uint32_t defer_entries = 4;     // >0: deferred-triangle schedule with this many parked groups per lane

@@ -600,7 +600,7 @@ def test_count_kernel_matches_host_walker_on_the_same_bvh8(ctx, oracle, pairs):
     finally:
         ctx.set_option(api.PT_OPT_COUNT_TRAVERSAL, 0)
         ctx.set_option(api.PT_OPT_EXTEND_DEFER, 4)
-        ctx.set_option(api.PT_OPT_EXTEND_POSTPONE_PCT, 50)
+        ctx.set_option(api.PT_OPT_EXTEND_POSTPONE_PCT, 40)
     assert np.array_equal(got.view(np.uint32), whits.view(np.uint32))
     assert (st.nodes_visited, st.tris_tested) == (cn.value, ct.value)
     assert 5 < cn.value / len(rays) < 60 and 1 < ct.value / len(rays) < 40
@@ -709,7 +709,7 @@ def test_extend_schedule_options_never_change_hits(ctx, oracle, fetch_min, postp
     info = ctx.scene_info()
     rays = random_rays(31, 150000, list(info.bounds_min), list(info.bounds_max), tmin=0.001, tmax=10000.0)
     ref = osc.trace_rays(rays)
-    opts = ((api.PT_OPT_EXTEND_FETCH_MIN, fetch_min, 16), (api.PT_OPT_EXTEND_POSTPONE_PCT, postpone, 50),
+    opts = ((api.PT_OPT_EXTEND_FETCH_MIN, fetch_min, 16), (api.PT_OPT_EXTEND_POSTPONE_PCT, postpone, 40),
             (api.PT_OPT_EXTEND_BLOCKS_PER_CU, blocks, 0), (api.PT_OPT_EXTEND_LDS_STACK, lds_stack, 6),
             (api.PT_OPT_EXTEND_DEFER, defer, 4))
     try:
