@@ -63,6 +63,20 @@ __device__ __forceinline__ float raySphereIntersectNearest(v3 r0, v3 rd, v3 s0, 
   return fmaxf(0.0f, fminf(sol0, sol1));
 }
 
+// "raySphereIntersectNearest(...) >= 0" as a predicate (the march's earth-shadow test, sky/Common.hlsl:519-521, only asks
+// whether there is a hit): with a = |rd|^2 > 0 the sign of each root is the sign of its numerator, so the two divisions
+// by 2a are not needed. Same delta and square root as the function above.
+__device__ __forceinline__ bool raySphereHits(v3 r0, v3 rd, v3 s0, float sR) {
+  float a = dot(rd, rd);
+  v3 s0_r0 = r0 - s0;
+  float b = 2.0f * dot(rd, s0_r0);
+  float c = dot(s0_r0, s0_r0) - (sR * sR);
+  float delta = b * b - 4.0f * a * c;
+  if (delta < 0.0f || a == 0.0f) return false;
+  float sq = sqrtf(delta);
+  return !((-b - sq) < 0.0f && (-b + sq) < 0.0f);
+}
+
 // LutTransmittanceParamsToUv — sky/Common.hlsl:103-117
 template <bool FAST>
 __device__ __forceinline__ v2 LutTransmittanceParamsToUv(float bottomR, float topR, float viewHeight, float mu) {
@@ -259,9 +273,11 @@ __device__ __forceinline__ v3 IntegrateSkyLuminance(v3 P0, v3 dir, v3 sunDir, co
   v3 throughput = mk3(1.0f);
   const float SampleSegmentT = 0.3f;
   v3 earthO = mk3(0.0f);
+  float t1_lin = 0.0f / SampleCountFloor;   // (s + 1) / SampleCountFloor of one step is s / SampleCountFloor of the next: one division per step
   for (float s = 0.0f; s < SampleCount; s += 1.0f) {
-    float t0 = (s) / SampleCountFloor;
+    float t0 = t1_lin;
     float t1 = (s + 1.0f) / SampleCountFloor;
+    t1_lin = t1;
     t0 = t0 * t0;
     t1 = t1 * t1;
     t0 = tMaxFloor * t0;
@@ -276,15 +292,16 @@ __device__ __forceinline__ v3 IntegrateSkyLuminance(v3 P0, v3 dir, v3 sunDir, co
     v3 SampleTransmittance = mk3(sky_exp<true>(-SampleOpticalDepth.x), sky_exp<true>(-SampleOpticalDepth.y), sky_exp<true>(-SampleOpticalDepth.z));
 
     float pHeight = length(P);
-    v3 UpVector = P / pHeight;
+    // the unit up vector feeds the LUT coordinate and the 10 m lift of the shadow sphere, not a height: reciprocal form
+    const float rcpHeight = sky_div<true>(1.0f, pHeight);
+    v3 UpVector = PT_SKY_LIBM_FORMS ? P / pHeight : P * rcpHeight;
     float SunZenithCosAngle = dot(sunDir, UpVector);
     v2 uv = LutTransmittanceParamsToUv<true>(A.BottomRadius, A.TopRadius, pHeight, SunZenithCosAngle);
     v3 TransmittanceToSun = SampleTransmittanceLut(lut, uv);
 
     v3 PhaseTimesScattering = medium.scatteringMie * MiePhaseValue + medium.scatteringRay * RayleighPhaseValue;
 
-    float tEarth = raySphereIntersectNearest(P, sunDir, earthO + PT_PLANET_RADIUS_OFFSET * UpVector, A.BottomRadius);
-    float earthShadow = tEarth >= 0.0f ? 0.0f : 1.0f;
+    float earthShadow = raySphereHits(P, sunDir, earthO + PT_PLANET_RADIUS_OFFSET * UpVector, A.BottomRadius) ? 0.0f : 1.0f;
     v3 multiScatteredLuminance = mk3(0.0f);
     float shadow = 1.0f;
     v3 S = globalL * (earthShadow * shadow * TransmittanceToSun * PhaseTimesScattering + multiScatteredLuminance * medium.scattering);
