@@ -42,6 +42,10 @@ __device__ __forceinline__ float sky_exp(float x) {
   return (FAST && !PT_SKY_LIBM_FORMS) ? __builtin_amdgcn_exp2f(x * 1.44269504088896340736f) : expf(x);
 }
 template <bool FAST>
+__device__ __forceinline__ float sky_sqrt(float x) {
+  return (FAST && !PT_SKY_LIBM_FORMS) ? __builtin_amdgcn_sqrtf(x) : sqrtf(x);
+}
+template <bool FAST>
 __device__ __forceinline__ float sky_div(float a, float b) {
   return (FAST && !PT_SKY_LIBM_FORMS) ? a * __builtin_amdgcn_rcpf(b) : a / b;
 }
@@ -73,7 +77,7 @@ __device__ __forceinline__ bool raySphereHits(v3 r0, v3 rd, v3 s0, float sR) {
   float c = dot(s0_r0, s0_r0) - (sR * sR);
   float delta = b * b - 4.0f * a * c;
   if (delta < 0.0f || a == 0.0f) return false;
-  float sq = sqrtf(delta);
+  float sq = sky_sqrt<true>(delta);
   return !((-b - sq) < 0.0f && (-b + sq) < 0.0f);
 }
 
@@ -81,9 +85,9 @@ __device__ __forceinline__ bool raySphereHits(v3 r0, v3 rd, v3 s0, float sR) {
 template <bool FAST>
 __device__ __forceinline__ v2 LutTransmittanceParamsToUv(float bottomR, float topR, float viewHeight, float mu) {
   float H = sqrtf(fmaxf(0.0f, topR * topR - bottomR * bottomR));
-  float rho = sqrtf(fmaxf(0.0f, viewHeight * viewHeight - bottomR * bottomR));
+  float rho = sky_sqrt<FAST>(fmaxf(0.0f, viewHeight * viewHeight - bottomR * bottomR));
   float discriminant = viewHeight * viewHeight * (mu * mu - 1.0f) + topR * topR;
-  float d = fmaxf(0.0f, (-viewHeight * mu + sqrtf(discriminant)));
+  float d = fmaxf(0.0f, (-viewHeight * mu + sky_sqrt<FAST>(discriminant)));
   float d_min = topR - viewHeight;
   float d_max = rho + H;
   v2 uv;
