@@ -137,7 +137,10 @@ __device__ __forceinline__ Medium sampleMediumRGB(v3 P, const Atmo& A) {
 // hgPhase == CornetteShanksMiePhaseFunction — sky/Common.hlsl:246-255
 __device__ __forceinline__ float hgPhase(float g, float cosTheta) {
   float k = 3.0f / (8.0f * PT_PI) * (1.0f - g * g) / (2.0f + g * g);
-  return k * (1.0f + cosTheta * cosTheta) / hlsl_pow(1.0f + g * g - 2.0f * g * -cosTheta, 1.5f);
+  const float x = 1.0f + g * g - 2.0f * g * -cosTheta;
+  // pow(x, 1.5) = x * sqrt(x) (x >= (1 - |g|)^2 >= 0; a negative x gives NaN either way): two roundings instead of OCML's powf
+  const float p15 = PT_SKY_LIBM_FORMS ? hlsl_pow(x, 1.5f) : x * sqrtf(x);
+  return k * (1.0f + cosTheta * cosTheta) / p15;
 }
 // RayleighPhase — sky/Common.hlsl:267-271
 __device__ __forceinline__ float RayleighPhase(float cosTheta) {
