@@ -13,7 +13,7 @@ struct DeviceScene {
   bool paired = false;                 // record format of `tris` (csrc/bvh8.h)
   const uint4* prim_data = nullptr;    // per global triangle id: i0,i1,i2 (global vertex ids), instance id
   const float4* vertex_normal = nullptr;
-  const float4* prim_shade = nullptr;  // 4 x float4 per global triangle id: {n0, instance id bits}, {n1, -}, {n2, -}, {emission, rgba8 bits}:
+  const float4* prim_shade = nullptr;  // 4 x float4 per global triangle id: {n0, instance id bits}, {n1, colour r}, {n2, colour g}, {emission, colour b} (colour = decoded unorm, alpha unused):
                                        // everything ClosestHit loads, in ONE 64-byte record (one dependent fetch instead of three)
   const float2* vertex_uv = nullptr;
   const uint32_t* instance_material = nullptr;

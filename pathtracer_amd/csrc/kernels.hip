@@ -444,7 +444,7 @@ __global__ void __launch_bounds__(PT_SHADE_THREADS, PT_SHADE_MIN_WAVES) k_shade(
         const float baryZ = 1.0f - (bu + bv);
         v3 hitNormal = bu * mk3(n0.x, n0.y, n0.z) + bv * mk3(n1.x, n1.y, n1.z) + baryZ * mk3(n2.x, n2.y, n2.z);
         const v3 hitPos = origin + dir * hr.x;
-        v3 color = DecodeUnormRGB(__float_as_uint(mat.w));
+        v3 color = mk3(n1.w, n2.w, mat.w);   // Decode_Unorm_RGBA of the material colour, done at upload (pt_api.cpp)
         bool ggx = false;
         float roughness = 0.0f, metallic = 0.0f;
         if (EXT) {   // material extension (ggx_device.h): procedural albedo from the interpolated uv, GGX flag

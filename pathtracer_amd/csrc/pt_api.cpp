@@ -495,6 +495,13 @@ int pt_scene_create(pt_ctx* ctx, const PtMeshDesc* meshes, uint32_t num_meshes, 
       }
       memcpy(r + 3, &inst, 4);
       memcpy(r + 12, &inst_mat[4 * (size_t)inst], 16);
+      // Decode_Unorm_RGBA (byte / 255, R in the low byte) done here once, with the same IEEE division the kernel and the
+      // oracle would do per hit: r, g in the free lanes of the normal rows, b over the packed colour
+      uint32_t rgba;
+      memcpy(&rgba, r + 15, 4);
+      r[7] = (float)(rgba & 0xffu) / 255.0f;
+      r[11] = (float)((rgba >> 8) & 0xffu) / 255.0f;
+      r[15] = (float)((rgba >> 16) & 0xffu) / 255.0f;
     }
     PT_HIP(up(d_ps, rows.data(), rows.size() * 4));
   }
