@@ -26,6 +26,44 @@ static_assert(sizeof(PtRtConsts) == 288, "RtConsts is 288 bytes (PathTracer.cpp:
 // ------------------------------------------------------------------------------------------------ helpers
 __device__ __forceinline__ uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 
+// Streaming accesses (queue records, hit records, path state: touched once per bounce) carry the non-temporal hint, so
+// they do not push BVH nodes and ClosestHit rows out of L2 / Infinity Cache. PT_STREAM_NT=0 builds the plain forms.
+#ifndef PT_STREAM_NT
+#define PT_STREAM_NT 1
+#endif
+typedef float pt_f4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ld_stream(const float4* p) {
+#if PT_STREAM_NT
+  const pt_f4v v = __builtin_nontemporal_load((const pt_f4v*)p);
+  return make_float4(v.x, v.y, v.z, v.w);
+#else
+  return *p;
+#endif
+}
+__device__ __forceinline__ uint32_t ld_stream(const uint32_t* p) {
+#if PT_STREAM_NT
+  return __builtin_nontemporal_load(p);
+#else
+  return *p;
+#endif
+}
+__device__ __forceinline__ void st_stream(float4* p, float4 v) {
+#if PT_STREAM_NT
+  pt_f4v w;
+  w.x = v.x; w.y = v.y; w.z = v.z; w.w = v.w;
+  __builtin_nontemporal_store(w, (pt_f4v*)p);
+#else
+  *p = v;
+#endif
+}
+__device__ __forceinline__ void st_stream(uint32_t* p, uint32_t v) {
+#if PT_STREAM_NT
+  __builtin_nontemporal_store(v, p);
+#else
+  *p = v;
+#endif
+}
+
 // Wave-aggregated queue append: one atomic per wave. Must be called by all 64 lanes convergently.
 __device__ __forceinline__ uint32_t wave_append(uint32_t* counter, bool pred) {
   const unsigned long long mask = __ballot(pred);
@@ -169,6 +207,12 @@ __global__ void __launch_bounds__(256) k_extend(const uint4* __restrict__ nodes,
   uint32_t chunk = (n / (total_waves * 8u) + 63u) & ~63u;
   chunk = chunk < 64u ? 64u : (chunk > 2048u ? 2048u : chunk);
 
+#ifdef PT_EXP_XCD_AFFINITY
+  uint32_t xa_seg, xa_tried = 0u;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xa_seg));
+  xa_seg &= 7u;
+  const uint32_t xa_len = ((n + 7u) / 8u + 63u) & ~63u;
+#endif
   uint32_t pool_next = 0u, pool_end = 0u;   // wave-uniform
   bool exhausted = false;                   // wave-uniform
   bool wave_risky = false;                  // wave-uniform: a lane holds a ray that needs the overflow-safe box test
@@ -189,10 +233,25 @@ __global__ void __launch_bounds__(256) k_extend(const uint4* __restrict__ nodes,
       if (unsaved) {
         HitRec hr = tr.best;
         if (hr.prim == 0xFFFFFFFFu) hr.t = -1.0f;
-        hits[ray_i] = make_float4(hr.t, hr.u, hr.v, __uint_as_float(hr.prim));
+        st_stream(hits + ray_i, make_float4(hr.t, hr.u, hr.v, __uint_as_float(hr.prim)));
         unsaved = false;
       }
       if (pool_next >= pool_end) {
+#ifdef PT_EXP_XCD_AFFINITY   // experiment: the queue in 8 contiguous segments, one per XCD (its blocks claim there first, then steal)
+        for (;;) {
+          uint32_t base = 0u;
+          if (lane == 0u) base = atomicAdd(work_cursor + xa_seg * 8u, chunk);   // 8 cursors inside this bounce's own 256-byte counter line
+          base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+          const uint32_t s0 = xa_seg * xa_len, s1 = s0 + xa_len < n ? s0 + xa_len : n;
+          if (s0 < n && base < s1 - s0) {
+            pool_next = s0 + base;
+            pool_end = pool_next + chunk < s1 ? pool_next + chunk : s1;
+            break;
+          }
+          if (++xa_tried == 8u) { exhausted = true; break; }
+          xa_seg = (xa_seg + 1u) & 7u;
+        }
+#else
         uint32_t base = 0u;
         if (lane == 0u) base = atomicAdd(work_cursor, chunk);
         base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
@@ -202,6 +261,7 @@ __global__ void __launch_bounds__(256) k_extend(const uint4* __restrict__ nodes,
           pool_next = base;
           pool_end = base + chunk < n ? base + chunk : n;
         }
+#endif
       }
       if (!exhausted) {
         const uint32_t avail = pool_end - pool_next;
@@ -216,11 +276,11 @@ __global__ void __launch_bounds__(256) k_extend(const uint4* __restrict__ nodes,
             f.corner = mk3(g0.x, g0.y, g0.z); f.xAxis = mk3(g1.x, g1.y, g1.z); f.yAxis = mk3(g2.x, g2.y, g2.z); f.camPos = mk3(g3.x, g3.y, g3.z);
             f.w = __float_as_uint(g0.w); f.h = __float_as_uint(g1.w); f.wh = __float_as_uint(g2.w); f.first_sample = __float_as_uint(g3.w);
             v3 o, d;
-            (void)PrimaryRayOfPath(ray_i, f, o, d);
+            (void)PrimaryRayOfSlot(ray_i, f, o, d);   // hits[] stays indexed by the slot
             r.ox = o.x; r.oy = o.y; r.oz = o.z; r.tmin = 0.0f;          // TMin 0.0, TMax 10000 (PathTracing.hlsl:59-61)
             r.dx = d.x; r.dy = d.y; r.dz = d.z; r.tmax = 10000.0f;
           } else {
-            const float4 ro = ray_o[(size_t)ray_i * stride], rd = ray_d[(size_t)ray_i * stride];
+            const float4 ro = ld_stream(ray_o + (size_t)ray_i * stride), rd = ld_stream(ray_d + (size_t)ray_i * stride);
             r.ox = ro.x; r.oy = ro.y; r.oz = ro.z; r.tmin = ro.w;
             r.dx = rd.x; r.dy = rd.y; r.dz = rd.z; r.tmax = rd.w;
           }
@@ -362,7 +422,7 @@ __global__ void __launch_bounds__(256) k_extend(const uint4* __restrict__ nodes,
   if (unsaved) {   // rays that finished after the last refill
     HitRec hr = tr.best;
     if (hr.prim == 0xFFFFFFFFu) hr.t = -1.0f;
-    hits[ray_i] = make_float4(hr.t, hr.u, hr.v, __uint_as_float(hr.prim));
+    st_stream(hits + ray_i, make_float4(hr.t, hr.u, hr.v, __uint_as_float(hr.prim)));
   }
   if (COUNT) {
     atomicAdd(&stats[ST_NODES], (unsigned long long)n_nodes);
@@ -407,12 +467,12 @@ __global__ void __launch_bounds__(PT_SHADE_THREADS, PT_SHADE_MIN_WAVES) k_shade(
     uint32_t pid = 0u;
     v3 origin = mk3(0.0f), dir = mk3(0.0f), newOrigin = mk3(0.0f), newDir = mk3(0.0f);
     if (active) {
-      pid = qid_in ? qid_in[j] : j;
-      const float4 hr = hits[j];
+      pid = qid_in ? ld_stream(qid_in + j) : j;
+      const float4 hr = ld_stream(hits + j);
       if (FUSED) {
-        (void)PrimaryRayOfPath(j, pf, origin, dir);
+        pid = PrimaryRayOfSlot(j, pf, origin, dir);   // the slot order k_extend fetched in
       } else {
-        const float4 ro = ray_o_in[j], rd = ray_d_in[j];
+        const float4 ro = ld_stream(ray_o_in + j), rd = ld_stream(ray_d_in + j);
         origin = mk3(ro.x, ro.y, ro.z);
         dir = mk3(rd.x, rd.y, rd.z);
       }
@@ -469,7 +529,7 @@ __global__ void __launch_bounds__(PT_SHADE_THREADS, PT_SHADE_MIN_WAVES) k_shade(
         // ---- RayGen loop body: PathTracing.hlsl:83-127 ----
         float4 Ts;
         if (FUSED) Ts = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(2u));   // two jitter draws taken (Random.hlsl:96-99)
-        else Ts = st_T[pid];
+        else Ts = ld_stream(st_T + pid);
         v3 transmission = mk3(Ts.x, Ts.y, Ts.z);
         Rng rng;
         uint32_t pix, si;
@@ -522,7 +582,7 @@ __global__ void __launch_bounds__(PT_SHADE_THREADS, PT_SHADE_MIN_WAVES) k_shade(
           else transmission = transmission / q;
         }
         if (!last_bounce && alive) {
-          st_T[pid] = make_float4(transmission.x, transmission.y, transmission.z, __uint_as_float(rng.w));
+          st_stream(st_T + pid, make_float4(transmission.x, transmission.y, transmission.z, __uint_as_float(rng.w)));
           newOrigin = hitPos;   // :126
           want_ray = true;
         }
@@ -532,13 +592,13 @@ __global__ void __launch_bounds__(PT_SHADE_THREADS, PT_SHADE_MIN_WAVES) k_shade(
     uint32_t slot, sslot;
     block_append2(s_app, parity, &counters[CTR_AT(CTR_QCOUNT0 + bounce + 1)], want_ray, &counters[CTR_AT(CTR_SKY)], want_sky, slot, sslot);
     if (want_ray) {
-      ray_o_out[slot] = make_float4(newOrigin.x, newOrigin.y, newOrigin.z, 0.001f);  // TMin 0.001 (:127)
-      ray_d_out[slot] = make_float4(newDir.x, newDir.y, newDir.z, 10000.0f);
-      qid_out[slot] = pid;
+      st_stream(ray_o_out + slot, make_float4(newOrigin.x, newOrigin.y, newOrigin.z, 0.001f));  // TMin 0.001 (:127)
+      st_stream(ray_d_out + slot, make_float4(newDir.x, newDir.y, newDir.z, 10000.0f));
+      st_stream(qid_out + slot, pid);
     }
     if (want_sky) {
-      sky_o[sslot] = make_float4(origin.x, origin.y, origin.z, __uint_as_float(pid));
-      sky_d[sslot] = make_float4(dir.x, dir.y, dir.z, FUSED ? 1.0f : 0.0f);   // w != 0: T = 1 and L = 0, not in memory
+      st_stream(sky_o + sslot, make_float4(origin.x, origin.y, origin.z, __uint_as_float(pid)));
+      st_stream(sky_d + sslot, make_float4(dir.x, dir.y, dir.z, FUSED ? 1.0f : 0.0f));   // w != 0: T = 1 and L = 0, not in memory
     }
   }
   // one atomic per wave for the statistics

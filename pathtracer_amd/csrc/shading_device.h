@@ -49,10 +49,7 @@ __device__ __forceinline__ void GetPrimaryRay(v2 pixel, uint32_t resX, uint32_t 
 // jitter). One function for k_generate, the fused fetch of k_extend and bounce 0 of k_shade, so all three produce the
 // same bits. p = sample_in_batch * w*h + y*w + x; returns the RNG draw counter after the two jitter draws.
 struct PrimaryFrame { v3 corner, xAxis, yAxis, camPos; uint32_t w, h, wh, first_sample; };
-__device__ __forceinline__ uint32_t PrimaryRayOfPath(uint32_t p, const PrimaryFrame& f, v3& origin, v3& dir) {
-  uint32_t pix, si, px, py;
-  FastDiv(f.wh, 0x7fffffffu).divmod(p, si, pix);     // path ids stay below 2^31 (pt_api.cpp batch sizing)
-  FastDiv(f.w, f.wh).divmod(pix, py, px);
+__device__ __forceinline__ uint32_t PrimaryRayOfPixel(uint32_t px, uint32_t py, uint32_t si, const PrimaryFrame& f, v3& origin, v3& dir) {
   Rng rng = InitRNG(px, py, f.first_sample + si);
   v2 pixel;
   pixel.x = (float)px;
@@ -65,6 +62,34 @@ __device__ __forceinline__ uint32_t PrimaryRayOfPath(uint32_t p, const PrimaryFr
   pixel.y = clampf(pixel.y, 0.0f, (float)f.h);
   GetPrimaryRay(pixel, f.w, f.h, f.corner, f.xAxis, f.yAxis, f.camPos, origin, dir);
   return rng.w;
+}
+__device__ __forceinline__ uint32_t PrimaryRayOfPath(uint32_t p, const PrimaryFrame& f, v3& origin, v3& dir) {
+  uint32_t pix, si, px, py;
+  FastDiv(f.wh, 0x7fffffffu).divmod(p, si, pix);     // path ids stay below 2^31 (pt_api.cpp batch sizing)
+  FastDiv(f.w, f.wh).divmod(pix, py, px);
+  return PrimaryRayOfPixel(px, py, si, f, origin, dir);
+}
+// Fused primaries only (no k_generate pass, so nothing else sees the order): slot j of the bounce-0 queue is not path j
+// but the path of an 8x8-pixel tile order within its sample, so the 64 consecutive slots a wave fetches are a square
+// footprint instead of a 64x1 strip (fewer distinct BVH nodes per box test). The path id -- what the RNG, the path state
+// and k_resolve are keyed on -- keeps its meaning p = sample * w*h + y*w + x, so the target bits do not change. Frames
+// whose width or height is not a multiple of 8 keep the identity order (wave-uniform test). Returns the path id.
+#ifndef PT_PRIMARY_TILES
+#define PT_PRIMARY_TILES 1
+#endif
+__device__ __forceinline__ uint32_t PrimaryRayOfSlot(uint32_t j, const PrimaryFrame& f, v3& origin, v3& dir) {
+  uint32_t r, si, px, py;
+  FastDiv(f.wh, 0x7fffffffu).divmod(j, si, r);
+  if (PT_PRIMARY_TILES && ((f.w | f.h) & 7u) == 0u) {
+    uint32_t ty, tx;
+    FastDiv(f.w >> 3, f.wh >> 6).divmod(r >> 6, ty, tx);
+    px = tx * 8u + (r & 7u);
+    py = ty * 8u + ((r >> 3) & 7u);
+  } else {
+    FastDiv(f.w, f.wh).divmod(r, py, px);
+  }
+  (void)PrimaryRayOfPixel(px, py, si, f, origin, dir);
+  return si * f.wh + py * f.w + px;
 }
 // GetLuminance — Common.hlsl:191-194
 __device__ __forceinline__ float GetLuminance(v3 c) { return dot(c, mk3(0.2126f, 0.7152f, 0.0722f)); }
