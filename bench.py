@@ -66,6 +66,8 @@ def main():
     ap.add_argument("--pipeline", type=int, default=0, choices=[0, 1],
                     help="1 = two pipeline lanes per batch (PT_OPT_PIPELINE): higher throughput, but extend launches then "
                          "overlap other kernels and the per-launch durations of the roofline grow")
+    ap.add_argument("--primary-packet", type=int, default=1, choices=[0, 1],
+                    help="PT_OPT_PRIMARY_PACKET: 1 (library default) = the coherent primaries are traced by k_extend_packet, 0 = by k_extend")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
@@ -143,6 +145,7 @@ def main():
     ctx.set_option(api.PT_OPT_SKY_MODE, args.sky_mode)
     ctx.set_option(api.PT_OPT_PIPELINE, args.pipeline)
     ctx.set_option(api.PT_OPT_RUSSIAN_ROULETTE, args.russian_roulette)
+    ctx.set_option(api.PT_OPT_PRIMARY_PACKET, args.primary_packet)
 
     total_steps = WU + K
     # this rank's sample indices: a contiguous block of (WU+K)*SPP samples

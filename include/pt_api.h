@@ -209,6 +209,8 @@ enum {
   PT_OPT_FUSED_PRIMARY = 14,       /* 0/1 (default 1): pt_render computes primary rays inside the traversal and shading kernels
                                       (RayGen's ray set-up, PathTracing.hlsl:40-61) instead of writing them to the bounce-0 queue
                                       and reading them back: 160 B of memory traffic per path less, results bit-identical */
+  PT_OPT_PRIMARY_PACKET = 15,      /* 0/1 (default 1): the fused primaries of pt_render (coherent 8x8-pixel tiles) are traced by one BVH walk
+                                      per wave with wave-uniform node fetches; 0 = by the general per-lane traversal kernel. Same hit records. */
   PT_OPT_PIPELINE = 11             /* 0/1 (default 0): split every batch of >= 2 samples into two halves that run on two streams (the
                                       second one internal): one half's shade kernels and kernel drains run under the other half's
                                       extend, +2..5 % throughput, results bit-identical; off by default because concurrent kernels

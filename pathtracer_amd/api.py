@@ -44,6 +44,7 @@ PT_OPT_PIPELINE = 11
 PT_OPT_EXTEND_TOP_NODES = 12
 PT_OPT_EXTEND_CONTINUE_PCT = 13
 PT_OPT_FUSED_PRIMARY = 14
+PT_OPT_PRIMARY_PACKET = 15
 
 (PT_FN_RAND01, PT_FN_FRESNEL, PT_FN_SPEC_PROB, PT_FN_SAMPLE_PHONG, PT_FN_EVAL_PHONG, PT_FN_COS_HEMISPHERE,
  PT_FN_LAMBERT, PT_FN_SKY, PT_FN_PRIMARY_RAY, PT_FN_SKY_VIEW_LUT, PT_FN_GGX_SAMPLE, PT_FN_ALBEDO_PATTERN) = range(12)

@@ -109,6 +109,10 @@ void launch_resolve(const WavefrontBuffers& wb, float4* accum, uint32_t w, uint3
 void launch_add(float4* dst, const float4* src, uint64_t n, hipStream_t s);   // dst[i] += src[i]
 void launch_set_count(uint32_t* counter, uint32_t value, hipStream_t s);
 void launch_debug_eval(int fn, const PtRtConsts& c, const uint2* lut, const float4* skyview, const float* in, uint64_t n, float* out, hipStream_t s);
+// k_extend_packet: one BVH walk per wave for coherent queues (fused primaries); blocks = CUs x extend_packet_occupancy_blocks
+void launch_extend_packet(const DeviceScene& sc, const float4* ray_o, const float4* ray_d, float4* hits, const uint32_t* count,
+                          uint32_t* work_cursor, int blocks, hipStream_t s, const float4* primary_gen);
+int extend_packet_occupancy_blocks(uint32_t stack_entries, bool paired);
 size_t extend_lds_bytes(uint32_t lds_entries_total, uint32_t top_nodes);
 int extend_occupancy_blocks(uint32_t lds_entries_total, uint32_t top_nodes, bool defer, bool paired);
 

@@ -169,10 +169,14 @@ __global__ void k_primary_setup(PtRtConsts c, float4* __restrict__ gen, uint32_t
 #ifndef PT_EXTEND_NODE_STEPS
 #define PT_EXTEND_NODE_STEPS 3   // box tests per scheduler iteration of the deferred schedule (1..4; C2 extend: 6.79, 6.95, 6.98, 6.83 Grays/s)
 #endif
-template <bool COUNT, bool DEFER, bool PAIRS>
-#ifdef PT_EXP_EXTEND_W6
-__attribute__((amdgpu_waves_per_eu(6)))
+// 6 waves per SIMD (80 VGPRs) for every instantiation: left to itself the register allocator lands between 78 and 90
+// VGPRs depending on small changes to the box test; at 6 waves with 3-5 spilled registers (scratch, cold paths) the
+// kernel is 1-3 % faster than at 5 waves without spills (tools/ab.sh).
+#ifndef PT_EXTEND_WAVES_PER_EU
+#define PT_EXTEND_WAVES_PER_EU 6
 #endif
+template <bool COUNT, bool DEFER, bool PAIRS>
+__attribute__((amdgpu_waves_per_eu(PT_EXTEND_WAVES_PER_EU, PT_EXTEND_WAVES_PER_EU)))
 __global__ void __launch_bounds__(256) k_extend(const uint4* __restrict__ nodes, const uint4* __restrict__ tris,
                                                 const float4* __restrict__ ray_o, const float4* __restrict__ ray_d,
                                                 float4* __restrict__ hits, const uint32_t* __restrict__ count_ptr,
@@ -430,6 +434,258 @@ __global__ void __launch_bounds__(256) k_extend(const uint4* __restrict__ nodes,
     if (lane == 0u) {
       atomicAdd(&stats[ST_NODE_WAVE_STEPS], (unsigned long long)n_node_steps);
       atomicAdd(&stats[ST_TRI_WAVE_STEPS], (unsigned long long)n_tri_steps);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ extend, coherent packets
+// Primary rays of a fused batch arrive as 8x8-pixel tiles (PrimaryRayOfSlot): the 64 rays of a wave share almost their
+// whole path through the tree. This kernel walks the BVH ONCE PER WAVE: the node index is wave-uniform, so the 80-byte node
+// and the triangle records come through the scalar cache into SGPRs (no per-lane gathers: the vector-memory pipe, which
+// k_extend shares its time with, is idle here), every lane tests its own ray against the 8 child boxes, the hit masks are
+// OR-ed across the wave and the wave descends into every child that ANY lane hits, nearest-first in the octant order of the
+// wave's first ray. One stack per wave (LDS, 8 bytes per entry), no refill, no deferral: all lanes are active in every box
+// and triangle test. A lane tests triangles its own ray's box test would have culled; the triangle test is exact and the
+// closest hit with the lower-id tie-break does not depend on the order or on extra candidates, so the hit records are
+// bit-identical to k_extend's (test_fused_primary_rays_are_bit_identical_to_the_generate_pass). Incoherent queues would
+// visit the union of 64 unrelated paths here: pt_render uses it for bounce 0 only.
+__device__ __forceinline__ uint32_t wave_or(uint32_t v) {
+  // OR across the 64 lanes with DPP row shifts and the two row broadcasts; lane 63 ends up with the total
+  v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);   // row_shr:1
+  v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);   // row_shr:2
+  v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);   // row_shr:4
+  v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);   // row_shr:8
+  v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, true);   // row_bcast:15 into rows 1 and 3
+  v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, true);   // row_bcast:31 into rows 2 and 3
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+// Box tests of one node for a COHERENT wave (all rays in one octant): what depends on the node alone — near / far plane
+// choice, child bits and mask positions — is wave-uniform and compiles to scalar instructions; a lane spends its vector
+// instructions on the 48 plane FMAs, the min / max reductions and the 8 compares, and a child enters the wave's hit mask
+// when any lane's ray touches its box (the compare's lane mask is non-zero). A CU has ONE scalar unit for its four SIMDs
+// (one instruction per cycle), so the split is balanced rather than "everything uniform on the scalar side": the byte
+// -> half expansion of the 12 plane dwords is pinned to the vector pipe (a full-rate v_and_b32 and a v_perm_b32 each),
+// and the hit mask is assembled from an 8-bit child mask, visiting only the children that were hit.
+typedef _Float16 pt_h2u __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t packet_child_tests(uint32_t meta_lo, uint32_t meta_hi, const uint2& pnx, const uint2& pny, const uint2& pnz,
+                                                       const uint2& pfx, const uint2& pfy, const uint2& pfz, float ax, float ay, float az, float bx,
+                                                       float by, float bz, uint32_t oct4, float tmin, float bestt) {
+  // pn* / pf*: the near / far plane dwords of the wave's octant (children 0-3 in .x, 4-7 in .y), fetched in that order
+  const float btk = bestt * 1.000001f;   // the ~8 ulp widening of the far side (as in Traverser::child_tests), once per node
+  uint32_t hit8 = 0u;                    // bit (7 - c): child c = 4 h + j was hit by some lane
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const uint32_t nx = h ? pnx.y : pnx.x, ny = h ? pny.y : pny.x, nz = h ? pnz.y : pnz.x;
+    const uint32_t fx = h ? pfx.y : pfx.x, fy = h ? pfy.y : pfy.x, fz = h ? pfz.y : pfz.x;
+    // bytes (0, 2) and (1, 3) of a plane dword as the halves of one register: binary16 denormals, exactly byte * 2^-24
+    uint32_t e_[6], o_[6];
+    const uint32_t q_[6] = {nx, ny, nz, fx, fy, fz};
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+      asm("v_and_b32 %0, %1, %2" : "=v"(e_[a]) : "s"(q_[a]), "v"(0x00ff00ffu));
+      asm("v_perm_b32 %0, 0, %1, %2" : "=v"(o_[a]) : "s"(q_[a]), "v"(0x0c030c01u));
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int k = j >> 1;
+#define PT_PK_PLANE(a) (float)(__builtin_bit_cast(pt_h2u, (j & 1) ? o_[a] : e_[a])[k])
+      const float tnx = __builtin_fmaf(PT_PK_PLANE(0), ax, bx);
+      const float tny = __builtin_fmaf(PT_PK_PLANE(1), ay, by);
+      const float tnz = __builtin_fmaf(PT_PK_PLANE(2), az, bz);
+      const float tfx = __builtin_fmaf(PT_PK_PLANE(3), ax, bx);
+      const float tfy = __builtin_fmaf(PT_PK_PLANE(4), ay, by);
+      const float tfz = __builtin_fmaf(PT_PK_PLANE(5), az, bz);
+#undef PT_PK_PLANE
+      const float tn = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, tmin));
+      const float tf = fminf(fminf(tfx, tfy), tfz);
+      const bool hit = tn <= fminf(tf * 1.000001f, btk);
+      // hit8 = 2 hit8 + (some lane hit): the compare's lane mask against zero sets SCC, the add-with-carry shifts it in
+      asm volatile("s_cmp_lg_u64 %1, 0\n\ts_addc_u32 %0, %0, %0" : "+s"(hit8) : "s"(__ballot(hit)) : "scc");
+    }
+  }
+  uint32_t hm = 0u;
+  while (hit8 != 0u) {   // wave-uniform, scalar: the children some lane hit (two or three of eight, typically)
+    const int c = 7 - (31 - __clz((int)hit8));   // highest set bit first: child 0 sits at bit 7
+    hit8 &= ~(0x80u >> c);
+    const uint32_t meta4 = c >= 4 ? meta_hi : meta_lo;
+    const uint32_t meta = (meta4 >> (8 * (c & 3))) & 0xffu;
+    const uint32_t inner = ((meta & (meta << 1)) & 0x10u) ? 7u : 0u;
+    hm |= (meta >> 5) << ((meta ^ (oct4 & inner)) & 0x1fu);
+  }
+  return hm;
+}
+
+#ifndef PT_PACKET_WAVES_PER_EU
+#define PT_PACKET_WAVES_PER_EU 8   // 64 VGPRs: the coherent path fits; the rarely taken per-lane fallback spills 10 registers (6 / 7 / 8 waves: 10.97 / 11.10 / 11.18 Grays/s)
+#endif
+template <bool PAIRS>
+__attribute__((amdgpu_waves_per_eu(PT_PACKET_WAVES_PER_EU, PT_PACKET_WAVES_PER_EU)))
+__global__ void __launch_bounds__(256) k_extend_packet(const uint4* __restrict__ nodes, const uint4* __restrict__ tris,
+                                                       const float4* __restrict__ ray_o, const float4* __restrict__ ray_d,
+                                                       float4* __restrict__ hits, const uint32_t* __restrict__ count_ptr,
+                                                       uint32_t* __restrict__ work_cursor, uint32_t stack_entries, float scene_mag,
+                                                       const float4* __restrict__ gen) {
+  extern __shared__ uint2 s_stack[];
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  lds_u2* stk = (lds_u2*)s_stack + (size_t)wave * stack_entries;
+  const uint32_t n = *count_ptr;
+  const uint32_t total_waves = gridDim.x * (blockDim.x >> 6);
+  uint32_t chunk = (n / (total_waves * 8u) + 63u) & ~63u;
+  chunk = chunk < 64u ? 64u : (chunk > 2048u ? 2048u : chunk);
+  PrimaryFrame f;
+  if (gen != nullptr) {
+    const float4 g0 = gen[0], g1 = gen[1], g2 = gen[2], g3 = gen[3];
+    f.corner = mk3(g0.x, g0.y, g0.z); f.xAxis = mk3(g1.x, g1.y, g1.z); f.yAxis = mk3(g2.x, g2.y, g2.z); f.camPos = mk3(g3.x, g3.y, g3.z);
+    f.w = __float_as_uint(g0.w); f.h = __float_as_uint(g1.w); f.wh = __float_as_uint(g2.w); f.first_sample = __float_as_uint(g3.w);
+  }
+  for (;;) {
+    uint32_t base = 0u;
+    if (lane == 0u) base = atomicAdd(work_cursor, chunk);
+    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+    if (base >= n) break;
+    const uint32_t end = base + chunk < n ? base + chunk : n;
+    for (uint32_t tile = base; tile < end; tile += 64u) {   // wave-uniform
+      const uint32_t ray_i = tile + lane;
+      const bool valid = ray_i < end;
+      TraceRay r;
+      r.ox = 0.0f; r.oy = 0.0f; r.oz = 0.0f; r.tmin = 0.0f; r.dx = 0.0f; r.dy = 0.0f; r.dz = 1.0f; r.tmax = -1.0f;   // a ray that hits nothing
+      if (valid) {
+        if (gen != nullptr) {
+          v3 o, d;
+          (void)PrimaryRayOfSlot(ray_i, f, o, d);
+          r.ox = o.x; r.oy = o.y; r.oz = o.z; r.tmin = 0.0f;          // TMin 0.0, TMax 10000 (PathTracing.hlsl:59-61)
+          r.dx = d.x; r.dy = d.y; r.dz = d.z; r.tmax = 10000.0f;
+        } else {
+          const float4 ro = ld_stream(ray_o + ray_i), rd = ld_stream(ray_d + ray_i);
+          r.ox = ro.x; r.oy = ro.y; r.oz = ro.z; r.tmin = ro.w;
+          r.dx = rd.x; r.dy = rd.y; r.dz = rd.z; r.tmax = rd.w;
+        }
+        const float chk = (r.ox + r.oy + r.oz) + (r.dx + r.dy + r.dz);
+        if (!isfinite(chk)) { r.ox = 0.0f; r.oy = 0.0f; r.oz = 0.0f; r.tmin = 0.0f; r.dx = 0.0f; r.dy = 0.0f; r.dz = 1.0f; r.tmax = -1.0f; }   // as k_extend: a miss
+      }
+      Traverser tr;
+      tr.init(r, scene_mag);
+      const bool wave_risky = __ballot(tr.risky) != 0ull;
+      // traversal order and the bit positions of the hit mask: the octant of the wave's first ray, for every lane (the
+      // near / far planes of the slab test stay each lane's own)
+      const uint32_t oct = (uint32_t)__builtin_amdgcn_readfirstlane((int)tr.oct);
+      const uint32_t oct4 = oct * 0x01010101u;
+      const bool negx = tr.idx < 0.0f, negy = tr.idy < 0.0f, negz = tr.idz < 0.0f;
+      // coherent wave: every lane in the first ray's octant, with the same dominant axis and winding of the triangle test,
+      // and no lane on the overflow-safe box test; then the per-node and per-triangle selections below are scalar
+      const bool wnegx = (oct & 1u) != 0u, wnegy = (oct & 2u) != 0u, wnegz = (oct & 4u) != 0u;
+      const int wkx = __builtin_amdgcn_readfirstlane(tr.tt.kx), wky = __builtin_amdgcn_readfirstlane(tr.tt.ky), wkz = __builtin_amdgcn_readfirstlane(tr.tt.kz);
+      const bool coherent = !wave_risky && __ballot(tr.oct != oct || tr.tt.kx != wkx || tr.tt.ky != wky || tr.tt.kz != wkz) == 0ull;
+      // the ray origin in the triangle test's axis order (coherent waves: the same permutation for every lane)
+      const float okx = sel3(tr.tt.ox, tr.tt.oy, tr.tt.oz, wkx), oky = sel3(tr.tt.ox, tr.tt.oy, tr.tt.oz, wky), okz = sel3(tr.tt.ox, tr.tt.oy, tr.tt.oz, wkz);
+      // where the octant's near / far plane dwords sit among the node's six plane pairs (lo x, y, z, hi x, y, z): the
+      // selection is done by the scalar loads' addresses, once per tile, not by selects per node
+      const uint32_t inx = wnegx ? 3u : 0u, iny = wnegy ? 4u : 1u, inz = wnegz ? 5u : 2u;
+      const uint32_t ifx = wnegx ? 0u : 3u, ify = wnegy ? 1u : 4u, ifz = wnegz ? 2u : 5u;
+      uint32_t ngx = 0u, ngy = 0x80000000u;   // wave-uniform pending node group (root)
+      uint32_t sp = 0u;
+      for (;;) {
+        if (ngy <= 0x00FFFFFFu) {
+          if (sp == 0u) break;
+          --sp;
+          const pt_u2v e = stk[sp];
+          ngx = (uint32_t)__builtin_amdgcn_readfirstlane((int)e.x);
+          ngy = (uint32_t)__builtin_amdgcn_readfirstlane((int)e.y);
+        }
+        const uint32_t hitsw = ngy;
+        const int b = 31 - __clz((int)hitsw);
+        ngy &= ~(1u << b);
+        if (ngy > 0x00FFFFFFu) {
+          pt_u2v e;
+          e.x = ngx; e.y = ngy;
+          if (lane == 0u) stk[sp] = e;
+          ++sp;
+        }
+        const uint32_t slot = ((uint32_t)b - 24u) ^ oct;
+        const uint32_t rel = __popc(hitsw & ~(0xFFFFFFFFu << slot));
+        const uint32_t ni = (uint32_t)__builtin_amdgcn_readfirstlane((int)(ngx + rel));
+        const uint4* np = nodes + (size_t)ni * PT_NODE_STRIDE_U4;
+        const uint4 n0 = np[0], n1 = np[1];
+        const uint32_t e = n0.w;
+        const float px = __uint_as_float(n0.x) - tr.ray.ox, py = __uint_as_float(n0.y) - tr.ray.oy, pz = __uint_as_float(n0.z) - tr.ray.oz;
+        uint32_t hm;
+        if (coherent) {
+#if PT_MIX_FMA
+          const float sx = __uint_as_float(((e & 0xffu) << 23) + 0x0C000000u), sy = __uint_as_float((((e >> 8) & 0xffu) << 23) + 0x0C000000u),
+                      sz = __uint_as_float((((e >> 16) & 0xffu) << 23) + 0x0C000000u);
+          const uint2* pl = (const uint2*)(np + 2);
+          hm = packet_child_tests(n1.z, n1.w, pl[inx], pl[iny], pl[inz], pl[ifx], pl[ify], pl[ifz], sx * tr.idx, sy * tr.idy, sz * tr.idz, px * tr.idx,
+                                  py * tr.idy, pz * tr.idz, oct4, tr.ray.tmin, tr.best.t);
+#else
+#error "k_extend_packet's coherent path is written for PT_MIX_FMA"
+#endif
+        } else {
+          const uint4 n2 = np[2], n3 = np[3], n4 = np[4];
+          uint32_t hitmask = 0u;
+          if (wave_risky && tr.risky) {
+            const float sx = __uint_as_float((e & 0xffu) << 23), sy = __uint_as_float(((e >> 8) & 0xffu) << 23), sz = __uint_as_float(((e >> 16) & 0xffu) << 23);
+            tr.template child_tests<true>(n1, n2, n3, n4, sx, sy, sz, px, py, pz, negx, negy, negz, oct4, hitmask);
+          } else {
+#if PT_MIX_FMA
+            const float sx = __uint_as_float(((e & 0xffu) << 23) + 0x0C000000u), sy = __uint_as_float((((e >> 8) & 0xffu) << 23) + 0x0C000000u),
+                        sz = __uint_as_float((((e >> 16) & 0xffu) << 23) + 0x0C000000u);
+#else
+            const float sx = __uint_as_float((e & 0xffu) << 23), sy = __uint_as_float(((e >> 8) & 0xffu) << 23), sz = __uint_as_float(((e >> 16) & 0xffu) << 23);
+#endif
+            tr.template child_tests<false>(n1, n2, n3, n4, sx * tr.idx, sy * tr.idy, sz * tr.idz, px * tr.idx, py * tr.idy, pz * tr.idz, negx, negy, negz,
+                                           oct4, hitmask);
+          }
+          hm = wave_or(hitmask);
+        }
+        ngx = n1.x;
+        ngy = (hm & 0xFF000000u) | (e >> 24);
+        const uint32_t tbase = n1.y;
+        uint32_t tbits = hm & 0x00FFFFFFu;
+        while (tbits != 0u) {   // wave-uniform: every record some lane's box test let through
+          const uint32_t ti = tbase + (uint32_t)(__ffs((int)tbits) - 1);
+          tbits &= tbits - 1u;
+          const uint4* tp = tris + (size_t)ti * (PAIRS ? 4 : 3);
+          if (coherent) {
+            // the vertex components arrive in the wave's axis order: three scalar dword loads per vertex at offsets fixed per
+            // tile, no selects; the arithmetic is TriTester::shear's
+            const uint32_t* vp = (const uint32_t*)tp;
+#define PT_PK_SHEAR(v, S)                                                                                                  \
+            {                                                                                                                 \
+              (S).kz = __uint_as_float(vp[4 * (v) + wkz]) - okz;                                                              \
+              (S).x = (__uint_as_float(vp[4 * (v) + wkx]) - okx) - tr.tt.Sx * (S).kz;                                          \
+              (S).y = (__uint_as_float(vp[4 * (v) + wky]) - oky) - tr.tt.Sy * (S).kz;                                          \
+            }
+            TriTester::Sheared A, B, C;
+            PT_PK_SHEAR(0, A) PT_PK_SHEAR(1, B) PT_PK_SHEAR(2, C)
+            tr.tt.test_sheared(A, B, C, vp[3], tr.ray.tmin, tr.best);
+            if (PAIRS && vp[7] != 0xFFFFFFFFu) {
+              TriTester::Sheared D;
+              PT_PK_SHEAR(3, D)
+              const uint32_t code = vp[11];
+              tr.tt.test_sheared(TriTester::pick(A, B, C, D, code & 3u), TriTester::pick(A, B, C, D, (code >> 2) & 3u),
+                                 TriTester::pick(A, B, C, D, (code >> 4) & 3u), vp[7], tr.ray.tmin, tr.best);
+            }
+#undef PT_PK_SHEAR
+            continue;
+          }
+          const uint4 q0 = tp[0], q1 = tp[1], q2 = tp[2];
+          uint4 q3 = make_uint4(0u, 0u, 0u, 0u);
+          if (PAIRS) q3 = tp[3];
+          if (PAIRS) {
+            (void)tr.tt.test(q0, q1, q2, q3, tr.ray.tmin, tr.best);
+          } else {
+            tr.tt.test_sheared(tr.tt.shear(__uint_as_float(q0.x), __uint_as_float(q0.y), __uint_as_float(q0.z)),
+                               tr.tt.shear(__uint_as_float(q1.x), __uint_as_float(q1.y), __uint_as_float(q1.z)),
+                               tr.tt.shear(__uint_as_float(q2.x), __uint_as_float(q2.y), __uint_as_float(q2.z)), q0.w, tr.ray.tmin, tr.best);
+          }
+        }
+      }
+      if (valid) {
+        HitRec hr = tr.best;
+        if (hr.prim == 0xFFFFFFFFu) hr.t = -1.0f;
+        st_stream(hits + ray_i, make_float4(hr.t, hr.u, hr.v, __uint_as_float(hr.prim)));
+      }
     }
   }
 }
@@ -925,6 +1181,27 @@ void launch_extend(const DeviceScene& sc, const float4* ray_o, const float4* ray
   }
 #undef PT_LAUNCH_EXTEND2
 #undef PT_LAUNCH_EXTEND
+}
+
+int extend_packet_occupancy_blocks(uint32_t stack_entries, bool paired) {
+  int nb = 0;
+  const size_t lds = (size_t)stack_entries * 4u * sizeof(uint2);
+  const hipError_t e = paired ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_extend_packet<true>, 256, lds)
+                              : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_extend_packet<false>, 256, lds);
+  if (e != hipSuccess || nb < 1) nb = 1;
+  return nb;
+}
+
+// Coherent queues only (the fused primaries of pt_render): one BVH walk per wave (k_extend_packet).
+void launch_extend_packet(const DeviceScene& sc, const float4* ray_o, const float4* ray_d, float4* hits, const uint32_t* count,
+                          uint32_t* work_cursor, int blocks, hipStream_t s, const float4* primary_gen) {
+  const size_t lds = (size_t)sc.stack_entries * 4u * sizeof(uint2);   // one 8-byte entry per BVH level and wave
+  if (sc.paired)
+    hipLaunchKernelGGL((k_extend_packet<true>), dim3(blocks), dim3(256), lds, s, sc.nodes, sc.tris, ray_o, ray_d, hits, count, work_cursor,
+                       sc.stack_entries, sc.scene_mag, primary_gen);
+  else
+    hipLaunchKernelGGL((k_extend_packet<false>), dim3(blocks), dim3(256), lds, s, sc.nodes, sc.tris, ray_o, ray_d, hits, count, work_cursor,
+                       sc.stack_entries, sc.scene_mag, primary_gen);
 }
 
 void launch_shade(const PtRtConsts& c, const DeviceScene& sc, const WavefrontBuffers& wb, int bounce, uint32_t w, uint32_t h,

@@ -68,6 +68,8 @@ struct pt_ctx {
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   bool pipeline = false;
   bool fused_primary = PT_DEFAULT_FUSED_PRIMARY != 0;   // PT_OPT_FUSED_PRIMARY
+  bool primary_packet = true;         // PT_OPT_PRIMARY_PACKET: fused primaries traced by k_extend_packet (one BVH walk per wave)
+  int packet_blocks = 0;              // its persistent grid (CUs x occupancy), looked up on first use per scene
   bool last_render_fused = false;     // the bounce-0 queue of the last pt_render was never written (pt_debug_read_queue)
   float4* ao_o = nullptr;       // AO pipeline: 16 rays per pixel-sample (origin,tmin / dir,tmax / hit records)
   float4* ao_d = nullptr;
@@ -262,14 +264,18 @@ int check_consts(pt_ctx* ctx, const PtRtConsts* c, bool need_sky) {
 }
 
 void extend_one(pt_ctx* ctx, const float4* ro, const float4* rd, uint32_t stride, float4* hits, const uint32_t* count, uint32_t* cursor, int bounce = 0,
-                bool any_hit = false, int lane = 0, const float4* primary_gen = nullptr) {
+                bool any_hit = false, int lane = 0, const float4* primary_gen = nullptr, bool packet = false) {
   const hipStream_t st = lane ? ctx->stream2 : ctx->stream;
   std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
   if (ctx->time_kernels) {
     ev = get_event_pair(ctx);
     (void)hipEventRecord(ev.first, st);
   }
-  if (lane) {
+  if (packet) {   // coherent queue (fused primaries): one BVH walk per wave, no per-lane stacks (no spill region, no statistics)
+    if (ctx->packet_blocks <= 0)
+      ctx->packet_blocks = ctx->cfg.num_cus * std::max(1, std::min(8, extend_packet_occupancy_blocks(ctx->ds.stack_entries, ctx->ds.paired)));
+    launch_extend_packet(ctx->ds, ro, rd, hits, count, cursor, ctx->packet_blocks, st, primary_gen);
+  } else if (lane) {
     DeviceScene ds2 = ctx->ds;
     ds2.spill = ctx->spill2;
     launch_extend(ds2, ro, rd, stride, hits, count, cursor, ctx->wb2.stats, ctx->count_traversal, any_hit, ctx->cfg, st, primary_gen);
@@ -402,6 +408,7 @@ int pt_set_option(pt_ctx* ctx, int option, int64_t value) {
       if (ctx->has_scene)
         ctx->cfg.extend_blocks = extend_grid(ctx);
       return PT_OK;
+    case PT_OPT_PRIMARY_PACKET: ctx->primary_packet = value != 0; return PT_OK;
     case PT_OPT_FUSED_PRIMARY:
       if (value != 0 && value != 1) return ctx->fail(PT_ERR_INVALID_ARG, "PT_OPT_FUSED_PRIMARY must be 0 or 1");
       ctx->fused_primary = value != 0;
@@ -545,6 +552,7 @@ int pt_scene_create(pt_ctx* ctx, const PtMeshDesc* meshes, uint32_t num_meshes, 
   for (int a = 0; a < 3; ++a) { in.bounds_min[a] = bvh.lo[a]; in.bounds_max[a] = bvh.hi[a]; }
   in.build_ms = bvh.build_ms;
   ctx->has_scene = true;
+  ctx->packet_blocks = 0;   // depends on the scene (stack depth, record format)
   return PT_OK;
 }
 
@@ -755,7 +763,7 @@ int pt_render(pt_ctx* ctx, const PtRtConsts* consts, uint32_t width, uint32_t he
       for (int l = 0; l < n_lanes; ++l) {
         WavefrontBuffers& wb = *wbs[l];
         extend_one(ctx, wb.ray_o[in], wb.ray_d[in], 1, wb.hits, wb.counters + CTR_AT(CTR_QCOUNT0 + b), wb.counters + CTR_AT(CTR_WORK0 + b), (int)b, false, l,
-                   (fused && b == 0) ? wb.gen : nullptr);
+                   (fused && b == 0) ? wb.gen : nullptr, /*packet=*/fused && b == 0 && ctx->primary_packet && !ctx->count_traversal);
         launch_shade(*consts, ctx->ds, wb, (int)b, width, height, first_lane[l], wh * k_lane[l], ctx->russian_roulette, ctx->cfg, streams[l], fused);
       }
     }

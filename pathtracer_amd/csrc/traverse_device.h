@@ -10,6 +10,9 @@
 #ifndef PT_MIX_FMA
 #define PT_MIX_FMA 1   // 1 = plane bytes enter the box test as binary16 denormals through v_fma_mix_f32 (see child_tests)
 #endif
+#ifndef PT_BOX_AND_PERM
+#define PT_BOX_AND_PERM 1   // 1 = even plane bytes through a full-rate v_and_b32, odd ones through v_perm_b32; 0 = two byte permutes
+#endif
 #ifndef PT_NODE_STRIDE_U4
 #define PT_NODE_STRIDE_U4 5   // device stride of a BVH node in 16-byte units (5 = packed 80-byte nodes)
 #endif
@@ -204,15 +207,22 @@ struct Traverser {
       // q * 2^-24; v_fma_mix_f32 widens it exactly), against coefficients pre-scaled by 2^24: q*2^-24 * (a*2^24) + b is
       // the same real number as q*a + b, rounded once either way, so the bits equal the convert-then-FMA form while two
       // planes share one byte-permute instead of one conversion each.
+      // Bytes 0 and 2 of a plane dword become the two halves of one register with a single full-rate AND, bytes 1 and 3 with
+      // one byte permute (tools/valurate: v_and_b32 issues in 2 cycles per wave, v_perm_b32 like most other VALU
+      // instructions in 4): h[0] = children (0, 2) of this half, h[1] = children (1, 3).
       typedef _Float16 pt_h2 __attribute__((ext_vector_type(2)));
       pt_h2 hnx[2], hny[2], hnz[2], hfx[2], hfy[2], hfz[2];
       if (!SAFE) {
-        hnx[0] = __builtin_bit_cast(pt_h2, __builtin_amdgcn_perm(0u, nx, 0x0c010c00u)); hnx[1] = __builtin_bit_cast(pt_h2, __builtin_amdgcn_perm(0u, nx, 0x0c030c02u));
-        hny[0] = __builtin_bit_cast(pt_h2, __builtin_amdgcn_perm(0u, ny, 0x0c010c00u)); hny[1] = __builtin_bit_cast(pt_h2, __builtin_amdgcn_perm(0u, ny, 0x0c030c02u));
-        hnz[0] = __builtin_bit_cast(pt_h2, __builtin_amdgcn_perm(0u, nz, 0x0c010c00u)); hnz[1] = __builtin_bit_cast(pt_h2, __builtin_amdgcn_perm(0u, nz, 0x0c030c02u));
-        hfx[0] = __builtin_bit_cast(pt_h2, __builtin_amdgcn_perm(0u, fx, 0x0c010c00u)); hfx[1] = __builtin_bit_cast(pt_h2, __builtin_amdgcn_perm(0u, fx, 0x0c030c02u));
-        hfy[0] = __builtin_bit_cast(pt_h2, __builtin_amdgcn_perm(0u, fy, 0x0c010c00u)); hfy[1] = __builtin_bit_cast(pt_h2, __builtin_amdgcn_perm(0u, fy, 0x0c030c02u));
-        hfz[0] = __builtin_bit_cast(pt_h2, __builtin_amdgcn_perm(0u, fz, 0x0c010c00u)); hfz[1] = __builtin_bit_cast(pt_h2, __builtin_amdgcn_perm(0u, fz, 0x0c030c02u));
+#define PT_H2_EVEN(q) __builtin_bit_cast(pt_h2, PT_BOX_AND_PERM ? ((q) & 0x00ff00ffu) : __builtin_amdgcn_perm(0u, (q), 0x0c020c00u))
+#define PT_H2_ODD(q) __builtin_bit_cast(pt_h2, __builtin_amdgcn_perm(0u, (q), 0x0c030c01u))
+        hnx[0] = PT_H2_EVEN(nx); hnx[1] = PT_H2_ODD(nx);
+        hny[0] = PT_H2_EVEN(ny); hny[1] = PT_H2_ODD(ny);
+        hnz[0] = PT_H2_EVEN(nz); hnz[1] = PT_H2_ODD(nz);
+        hfx[0] = PT_H2_EVEN(fx); hfx[1] = PT_H2_ODD(fx);
+        hfy[0] = PT_H2_EVEN(fy); hfy[1] = PT_H2_ODD(fy);
+        hfz[0] = PT_H2_EVEN(fz); hfz[1] = PT_H2_ODD(fz);
+#undef PT_H2_EVEN
+#undef PT_H2_ODD
       }
 #endif
 #pragma unroll
@@ -220,12 +230,12 @@ struct Traverser {
         float tnx, tny, tnz, tfx, tfy, tfz;
 #if PT_MIX_FMA
         if (!SAFE) {
-          tnx = __builtin_fmaf((float)hnx[j >> 1][j & 1], ax, bx);
-          tny = __builtin_fmaf((float)hny[j >> 1][j & 1], ay, by);
-          tnz = __builtin_fmaf((float)hnz[j >> 1][j & 1], az, bz);
-          tfx = __builtin_fmaf((float)hfx[j >> 1][j & 1], ax, bx);
-          tfy = __builtin_fmaf((float)hfy[j >> 1][j & 1], ay, by);
-          tfz = __builtin_fmaf((float)hfz[j >> 1][j & 1], az, bz);
+          tnx = __builtin_fmaf((float)hnx[j & 1][j >> 1], ax, bx);
+          tny = __builtin_fmaf((float)hny[j & 1][j >> 1], ay, by);
+          tnz = __builtin_fmaf((float)hnz[j & 1][j >> 1], az, bz);
+          tfx = __builtin_fmaf((float)hfx[j & 1][j >> 1], ax, bx);
+          tfy = __builtin_fmaf((float)hfy[j & 1][j >> 1], ay, by);
+          tfz = __builtin_fmaf((float)hfz[j & 1][j >> 1], az, bz);
         } else
 #endif
         {

@@ -1061,15 +1061,18 @@ def test_full_size_properties_1080p(ctx, oracle):
 
 
 # ---------------------------------------------------------------------------------------------- fused primaries
-@pytest.mark.parametrize("sky,ext", [(True, False), (False, False), (True, True)])
-def test_fused_primary_rays_are_bit_identical_to_the_generate_pass(ctx, oracle, sky, ext):
+@pytest.mark.parametrize("sky,ext,size", [(True, False, (200, 120)), (False, False, (200, 120)), (True, True, (200, 120)),
+                                          (True, False, (204, 118)), (True, False, (64, 8)), (True, False, (8, 72))])
+def test_fused_primary_rays_are_bit_identical_to_the_generate_pass(ctx, oracle, sky, ext, size):
     """PT_OPT_FUSED_PRIMARY (default): primaries are computed inside k_extend / k_shade and the path state starts as
     constants instead of a k_generate pass through memory. Same RayGen arithmetic (PathTracing.hlsl:40-61) in all
-    three places, so target sums, ray counts and per-bounce queues must not change by a bit; both pipeline settings."""
+    three places, so target sums, ray counts and per-bounce queues must not change by a bit; both pipeline settings.
+    Frames whose width and height are multiples of 8 fetch their fused primaries in 8x8-pixel tile order (PrimaryRayOfSlot,
+    shading_device.h), other frames in row order: both kinds, and the one-tile-row / one-tile-column edge cases."""
     sc = scenes.with_material_ext(scenes.atrium(1)) if ext else scenes.atrium(1)
     ctx.scene_create(sc)
     ctx.sky_set(oracle.earth_atmosphere())
-    w, h, spp = 200, 120, 5
+    (w, h), spp = size, 5
     c = lookat_consts(w, h, scenes.ATRIUM_CAM, depth=4)
     if not sky:
         c.mySampleSky = 0
