@@ -31,6 +31,11 @@ FP32_PEAK_TFLOPS = 157.3                           # MI355X_MICROARCH.md: peak f
 L1_PEAK_GBS = 39321.6                              # vector L1 return path: 64 B/clk/CU x 256 CUs x 2.4 GHz
 PMC_ROUND = "r02"                                  # profiles/<round>/pmc_traffic.json: counters of THIS build
 DEF_DEFER, DEF_POSTPONE = 4, 40                   # the library defaults (csrc/kernels.h LaunchCfg)
+# k_extend's own VALU roof: most of its vector instructions (min/max, compares, selects, shifts, byte permutes, v_fma_mix)
+# issue at HALF rate on gfx950 (tools/valurate -> profiles/r02/valu_issue_rates.txt); weighted over its node and triangle
+# steps that is 3.52 cycles per wave64 instruction per SIMD (tools/valu_mix.py -> profiles/r02/valu_mix_extend.txt)
+VALU_MIX_CYCLES_EXTEND = 3.52
+VALU_MIX_ROOF_GINSTR = 256 * 4 * 2.4 / VALU_MIX_CYCLES_EXTEND
 
 
 def make_workload(name):
@@ -192,19 +197,32 @@ def main():
         #     the CANONICAL schedule (nearest-first, every triangle group tested at once: no postponing / deferral), so
         #     the figure does not grow when a faster schedule visits a few more nodes. The shipped schedule's own
         #     counts are reported beside it.
-        def count_pass(defer, postpone):
+        def count_pass(defer, postpone, primaries_only=False):
             ctx.set_option(api.PT_OPT_EXTEND_DEFER, defer)
             ctx.set_option(api.PT_OPT_EXTEND_POSTPONE_PCT, postpone)
             ctx.stats_reset()
-            ctx.set_option(api.PT_OPT_COUNT_TRAVERSAL, 1)
-            step(total_steps)
+            ctx.set_option(api.PT_OPT_COUNT_TRAVERSAL, 1)   # (the counting pass traces bounce 0 with k_extend too)
+            if primaries_only:
+                pt.myMaxRecursionDepth = 0
+                ctx.render(pt.BuildRtConsts(), W, H, first0 + total_steps * SPP, SPP)
+                pt.myMaxRecursionDepth = depth
+            else:
+                step(total_steps)
             r = ctx.stats()
             ctx.set_option(api.PT_OPT_COUNT_TRAVERSAL, 0)
             return r
         sc_ = count_pass(0, 0)
-        nodes_per_ray = sc_.nodes_visited / max(1, sc_.rays)
-        tris_per_ray = sc_.tris_tested / max(1, sc_.rays)
         ship = count_pass(DEF_DEFER, DEF_POSTPONE)
+        cn, ct, cr = sc_.nodes_visited, sc_.tris_tested, sc_.rays
+        sn, st_, sr, snw, stw = ship.nodes_visited, ship.tris_tested, ship.rays, ship.node_wave_steps, ship.tri_wave_steps
+        if args.primary_packet and depth > 0:
+            # bounce 0 belongs to k_extend_packet: k_extend's per-ray figures are those of the secondary bounces (same samples
+            # traced to depth 0, subtracted)
+            p0, p1 = count_pass(0, 0, True), count_pass(DEF_DEFER, DEF_POSTPONE, True)
+            cn, ct, cr = cn - p0.nodes_visited, ct - p0.tris_tested, cr - p0.rays
+            sn, st_, sr, snw, stw = sn - p1.nodes_visited, st_ - p1.tris_tested, sr - p1.rays, snw - p1.node_wave_steps, stw - p1.tri_wave_steps
+        nodes_per_ray = cn / max(1, cr)
+        tris_per_ray = ct / max(1, cr)
         bytes_per_ray = NODE_BYTES * nodes_per_ray + TRI_BYTES * tris_per_ray + RAY_IO_BYTES
         # (2) extend-kernel time: HIP events on the ctx stream around every extend launch, K more steps
         ctx.stats_reset()
@@ -226,10 +244,16 @@ def main():
                         pmc = e
         except (OSError, ValueError, KeyError):
             pass
-        launches = max(1, se.extend_launches)
-        launch_s = se.extend_ms / launches * 1e-3
-        alg_bytes = bytes_per_ray * se.rays / launches
-        alg_flop = (NODE_FLOP * nodes_per_ray + TRI_FLOP * tris_per_ray) * se.rays / launches
+        # k_extend's launches: every bounce, or bounces >= 1 when the fused primaries went through k_extend_packet
+        packet = bool(args.primary_packet) and se.extend_launches_bounce[0] > 0
+        b_from = 1 if packet else 0
+        k_launches = max(1, sum(se.extend_launches_bounce[b_from:]))
+        k_ms = sum(se.extend_ms_bounce[b_from:])
+        k_rays = sum(se.rays_bounce[b_from:])
+        launches = k_launches
+        launch_s = k_ms / launches * 1e-3
+        alg_bytes = bytes_per_ray * k_rays / launches
+        alg_flop = (NODE_FLOP * nodes_per_ray + TRI_FLOP * tris_per_ray) * k_rays / launches
         hbm = {"algorithmic_bytes_per_launch": round(alg_bytes, 1), "achieved_gbs": round(alg_bytes / launch_s / 1e9, 2),
                "peak_gbs": HBM_PEAK_GBS, "ratio_to_hbm_peak": round(alg_bytes / launch_s / 1e9 / HBM_PEAK_GBS, 4),
                "note": "SURVEY 8(d) B_ray x rays; the BVH is served from L1/L2/Infinity Cache when it fits (C2 14.7 MB, C4 176 MB), "
@@ -246,10 +270,14 @@ def main():
             g = pmc["extend_valu_wave_instr_per_launch"] / launch_s / 1e9
             valu = {"wave_instr_per_launch": pmc["extend_valu_wave_instr_per_launch"],
                     "lanes_active_per_instr": pmc.get("extend_lanes_active_per_valu_instr"),
-                    "achieved_ginstr_per_s": round(g, 1), "peak_ginstr_per_s": VALU_PEAK_GINSTR, "frac": round(g / VALU_PEAK_GINSTR, 4)}
+                    "achieved_ginstr_per_s": round(g, 1), "peak_ginstr_per_s": VALU_PEAK_GINSTR, "frac": round(g / VALU_PEAK_GINSTR, 4),
+                    "mix_cycles_per_instr": VALU_MIX_CYCLES_EXTEND, "mix_roof_ginstr_per_s": round(VALU_MIX_ROOF_GINSTR, 1),
+                    "frac_of_mix_roof": round(min(1.0, g / VALU_MIX_ROOF_GINSTR), 4),
+                    "note": "peak = every instruction at the full rate (2 cycles per wave64 instruction per SIMD); the kernel's own mix is mostly "
+                            "half-rate instructions (profiles/%s/valu_issue_rates.txt, valu_mix_extend.txt), hence the mix roof" % PMC_ROUND}
         # vector-memory pipe (L1 -> VGPR return path): every wave-level load moves 64 lanes x its width whatever the lanes
         # do with it; steps of the shipped schedule (COUNT pass) x loads per step (node: 5 x 16 B, triangle: 16+12+12 B)
-        l1_bytes = (ship.node_wave_steps * 64.0 * 80.0 + ship.tri_wave_steps * 64.0 * 40.0) / max(1, ship.rays) * se.rays / launches
+        l1_bytes = (snw * 64.0 * 80.0 + stw * 64.0 * 40.0) / max(1, sr) * k_rays / launches
         vmem = {"l1_return_bytes_per_launch": round(l1_bytes, 1), "achieved_gbs": round(l1_bytes / launch_s / 1e9, 1),
                 "peak_gbs": L1_PEAK_GBS, "frac": round(l1_bytes / launch_s / 1e9 / L1_PEAK_GBS, 4),
                 "ta_busy_frac": pmc.get("extend_ta_busy_frac") if pmc else None, "td_busy_frac": pmc.get("extend_td_busy_frac") if pmc else None,
@@ -271,12 +299,17 @@ def main():
             **top, "kernel": "k_extend", "traffic": traffic,
             "hbm_algorithmic": hbm, "fabric": fabric, "valu_issue": valu, "vmem_pipe": vmem, "flops_algorithmic": flops,
             "nodes_per_ray": round(nodes_per_ray, 3), "tris_per_ray": round(tris_per_ray, 3),
-            "shipped_schedule": {"nodes_per_ray": round(ship.nodes_visited / max(1, ship.rays), 3),
-                                 "tris_per_ray": round(ship.tris_tested / max(1, ship.rays), 3),
-                                 "node_phase_lane_util": round(ship.nodes_visited / max(1, 64 * ship.node_wave_steps), 3),
-                                 "tri_phase_lane_util": round(ship.tris_tested / max(1, 64 * ship.tri_wave_steps), 3)},
+            "shipped_schedule": {"nodes_per_ray": round(sn / max(1, sr), 3),
+                                 "tris_per_ray": round(st_ / max(1, sr), 3),
+                                 "node_phase_lane_util": round(sn / max(1, 64 * snw), 3),
+                                 "tri_phase_lane_util": round(st_ / max(1, 64 * stw), 3)},
             "bytes_per_ray": round(bytes_per_ray, 1),
-            "launches": int(se.extend_launches), "avg_launch_ms": round(se.extend_ms / launches, 4),
+            "launches": int(k_launches), "avg_launch_ms": round(k_ms / launches, 4),
+            "primary_kernel": ({"kernel": "k_extend_packet", "launches": int(se.extend_launches_bounce[0]),
+                                "avg_launch_ms": round(se.extend_ms_bounce[0] / max(1, se.extend_launches_bounce[0]), 4),
+                                "mrays_per_s": round(se.rays_bounce[0] / max(se.extend_ms_bounce[0], 1e-9) / 1e3, 1),
+                                "note": "bounce 0 (coherent 8x8-pixel tiles): one BVH walk per wave, scalar node / triangle fetches"}
+                               if packet else None),
             "bytes_per_launch": round(alg_bytes, 1),
             "extend_share_of_render": round(se.extend_ms / max(se.render_ms, 1e-9), 4),
             "extend_mrays_per_s": round(se.rays / max(ext_s, 1e-12) / 1e6, 2),

@@ -173,6 +173,7 @@ typedef struct PtStats {
   double extend_ms_bounce[16];   /* extend-kernel time at bounce b (only when timing is on) */
   uint64_t node_wave_steps;      /* wave-level node steps (counting on): nodes_visited / (64*this) = lane utilisation */
   uint64_t tri_wave_steps;       /* wave-level triangle steps (counting on) */
+  uint64_t extend_launches_bounce[16]; /* traversal-kernel launches at bounce b (bounce 0 of a fused pt_render: k_extend_packet) */
 } PtStats;
 
 typedef struct PtSceneInfo {

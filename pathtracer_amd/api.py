@@ -123,7 +123,8 @@ class PtStats(C.Structure):
                 ("nodes_visited", C.c_uint64), ("tris_tested", C.c_uint64), ("extend_launches", C.c_uint64),
                 ("extend_ms", C.c_double), ("render_ms", C.c_double),
                 ("rays_bounce", C.c_uint64 * 16), ("extend_ms_bounce", C.c_double * 16),
-                ("node_wave_steps", C.c_uint64), ("tri_wave_steps", C.c_uint64)]
+                ("node_wave_steps", C.c_uint64), ("tri_wave_steps", C.c_uint64),
+                ("extend_launches_bounce", C.c_uint64 * 16)]
 
 
 class PtSceneInfo(C.Structure):

@@ -83,6 +83,7 @@ struct LaunchCfg {
   int extend_blocks_per_cu = 0; // 0 = from the occupancy query
   uint32_t lds_stack_entries = 6; // per-lane stack entries kept in LDS; deeper entries spill to global memory
   uint32_t defer_entries = 4;     // >0: deferred-triangle schedule with this many parked groups per lane
+  bool no_private_segment = false; // launch the extend instantiation that uses no scratch memory (pt_trace_rays_device_noalloc)
   uint32_t top_nodes = 73;        // nodes of the tree's top (breadth-first order: 1 + 8 + 64) kept in LDS by every extend block
 };
 
@@ -114,6 +115,6 @@ void launch_extend_packet(const DeviceScene& sc, const float4* ray_o, const floa
                           uint32_t* work_cursor, int blocks, hipStream_t s, const float4* primary_gen);
 int extend_packet_occupancy_blocks(uint32_t stack_entries, bool paired);
 size_t extend_lds_bytes(uint32_t lds_entries_total, uint32_t top_nodes);
-int extend_occupancy_blocks(uint32_t lds_entries_total, uint32_t top_nodes, bool defer, bool paired);
+int extend_occupancy_blocks(uint32_t lds_entries_total, uint32_t top_nodes, bool defer, bool paired, bool no_private_segment = false);
 
 }  // namespace pt

@@ -169,274 +169,24 @@ __global__ void k_primary_setup(PtRtConsts c, float4* __restrict__ gen, uint32_t
 #ifndef PT_EXTEND_NODE_STEPS
 #define PT_EXTEND_NODE_STEPS 3   // box tests per scheduler iteration of the deferred schedule (1..4; C2 extend: 6.79, 6.95, 6.98, 6.83 Grays/s)
 #endif
-// 6 waves per SIMD (80 VGPRs) for every instantiation: left to itself the register allocator lands between 78 and 90
-// VGPRs depending on small changes to the box test; at 6 waves with 3-5 spilled registers (scratch, cold paths) the
-// kernel is 1-3 % faster than at 5 waves without spills (tools/ab.sh).
+// 6 waves per SIMD (80 VGPRs) pinned: left to itself the register allocator lands between 78 and 90 VGPRs depending on
+// small changes to the box test; at 6 waves with 3-5 registers spilled to the private segment (cold paths) the kernel is
+// 1-3 % faster than at 5 waves without spills (tools/ab.sh).
 #ifndef PT_EXTEND_WAVES_PER_EU
 #define PT_EXTEND_WAVES_PER_EU 6
 #endif
-template <bool COUNT, bool DEFER, bool PAIRS>
-__attribute__((amdgpu_waves_per_eu(PT_EXTEND_WAVES_PER_EU, PT_EXTEND_WAVES_PER_EU)))
-__global__ void __launch_bounds__(256) k_extend(const uint4* __restrict__ nodes, const uint4* __restrict__ tris,
-                                                const float4* __restrict__ ray_o, const float4* __restrict__ ray_d,
-                                                float4* __restrict__ hits, const uint32_t* __restrict__ count_ptr,
-                                                uint32_t* __restrict__ work_cursor, unsigned long long* __restrict__ stats,
-                                                uint32_t lds_entries, uint32_t spill_entries, uint2* __restrict__ spill, uint32_t stride, uint32_t fetch_min,
-                                                uint32_t postpone_pct, uint32_t dq_entries, uint32_t any_hit, float scene_mag, uint32_t top_nodes, uint32_t continue_pct,
-                                                const float4* __restrict__ gen) {
-  // gen != nullptr: the queue is the batch's primary rays, computed here from the path index (k_primary_setup)
-  // any_hit (wave-uniform): a ray ends at the first accepted intersection (occlusion queries: Ao.hlsl's ClosestHitAo
-  // only reports that something was hit). Only "prim != miss" is then defined in the hit record.
-  extern __shared__ uint2 s_stack[];
-  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-  LaneStack stk;
-  stk.lds = (lds_u2*)s_stack + (size_t)wave * lds_entries * 64u + lane;
-  stk.spill = (glb_u2*)spill + ((size_t)blockIdx.x * (blockDim.x >> 6) + wave) * spill_entries * 64u + lane;
-  stk.lds_entries = (int)lds_entries;
-  // DEFER: per-lane queue of deferred triangle groups, in LDS behind the stacks of the block's waves
-  uint2* dq = s_stack + (size_t)(blockDim.x >> 6) * lds_entries * 64u + (size_t)wave * dq_entries * 64u + lane;
-  uint32_t dqn = 0u;
-  // the top of the tree (first top_nodes nodes, breadth-first order), copied into LDS once per block
-  lds_u4* s_top = (lds_u4*)((lds_u2*)s_stack + (size_t)(blockDim.x >> 6) * (lds_entries + dq_entries) * 64u);
-  for (uint32_t i = threadIdx.x; i < top_nodes * PT_NODE_STRIDE_U4; i += blockDim.x) {
-    const uint4 v = nodes[i];
-    pt_u4v w;
-    w.x = v.x; w.y = v.y; w.z = v.z; w.w = v.w;
-    s_top[i] = w;
-  }
-  __syncthreads();
-  const uint32_t n = *count_ptr;
-  // chunk: large enough to amortise the atomic, small enough to balance the tail (~8 chunks per wave)
-  const uint32_t total_waves = gridDim.x * (blockDim.x >> 6);
-  uint32_t chunk = (n / (total_waves * 8u) + 63u) & ~63u;
-  chunk = chunk < 64u ? 64u : (chunk > 2048u ? 2048u : chunk);
-
-#ifdef PT_EXP_XCD_AFFINITY
-  uint32_t xa_seg, xa_tried = 0u;
-  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xa_seg));
-  xa_seg &= 7u;
-  const uint32_t xa_len = ((n + 7u) / 8u + 63u) & ~63u;
-#endif
-  uint32_t pool_next = 0u, pool_end = 0u;   // wave-uniform
-  bool exhausted = false;                   // wave-uniform
-  bool wave_risky = false;                  // wave-uniform: a lane holds a ray that needs the overflow-safe box test
-  bool busy = false;
-  bool unsaved = false;                     // this lane's finished ray still has its hit record in registers
-  uint32_t ray_i = 0u;
-  Traverser tr;
-  uint32_t n_nodes = 0u, n_tris = 0u, n_node_steps = 0u, n_tri_steps = 0u;   // *_steps: wave-level, lane 0 only
-
-  for (;;) {
-    // ---- refill idle lanes from the wave's pool ----
-    const unsigned long long idle_mask = __ballot(!busy);
-    const uint32_t n_idle = (uint32_t)__popcll(idle_mask);
-    if (n_idle == 64u && exhausted) break;
-    if (!exhausted && (n_idle >= fetch_min)) {
-      // Hit records of finished rays are written here, once per refill, by all the lanes that finished since the last
-      // one: a store per finishing lane per iteration costs the memory pipe one wave-instruction each time.
-      if (unsaved) {
-        HitRec hr = tr.best;
-        if (hr.prim == 0xFFFFFFFFu) hr.t = -1.0f;
-        st_stream(hits + ray_i, make_float4(hr.t, hr.u, hr.v, __uint_as_float(hr.prim)));
-        unsaved = false;
-      }
-      if (pool_next >= pool_end) {
-#ifdef PT_EXP_XCD_AFFINITY   // experiment: the queue in 8 contiguous segments, one per XCD (its blocks claim there first, then steal)
-        for (;;) {
-          uint32_t base = 0u;
-          if (lane == 0u) base = atomicAdd(work_cursor + xa_seg * 8u, chunk);   // 8 cursors inside this bounce's own 256-byte counter line
-          base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-          const uint32_t s0 = xa_seg * xa_len, s1 = s0 + xa_len < n ? s0 + xa_len : n;
-          if (s0 < n && base < s1 - s0) {
-            pool_next = s0 + base;
-            pool_end = pool_next + chunk < s1 ? pool_next + chunk : s1;
-            break;
-          }
-          if (++xa_tried == 8u) { exhausted = true; break; }
-          xa_seg = (xa_seg + 1u) & 7u;
-        }
-#else
-        uint32_t base = 0u;
-        if (lane == 0u) base = atomicAdd(work_cursor, chunk);
-        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-        if (base >= n) {
-          exhausted = true;
-        } else {
-          pool_next = base;
-          pool_end = base + chunk < n ? base + chunk : n;
-        }
-#endif
-      }
-      if (!exhausted) {
-        const uint32_t avail = pool_end - pool_next;
-        const uint32_t take = n_idle < avail ? n_idle : avail;
-        const uint32_t rank = (uint32_t)__popcll(idle_mask & ((1ull << lane) - 1ull));
-        if (!busy && rank < take) {
-          ray_i = pool_next + rank;
-          TraceRay r;
-          if (gen != nullptr) {
-            const float4 g0 = gen[0], g1 = gen[1], g2 = gen[2], g3 = gen[3];
-            PrimaryFrame f;
-            f.corner = mk3(g0.x, g0.y, g0.z); f.xAxis = mk3(g1.x, g1.y, g1.z); f.yAxis = mk3(g2.x, g2.y, g2.z); f.camPos = mk3(g3.x, g3.y, g3.z);
-            f.w = __float_as_uint(g0.w); f.h = __float_as_uint(g1.w); f.wh = __float_as_uint(g2.w); f.first_sample = __float_as_uint(g3.w);
-            v3 o, d;
-            (void)PrimaryRayOfSlot(ray_i, f, o, d);   // hits[] stays indexed by the slot
-            r.ox = o.x; r.oy = o.y; r.oz = o.z; r.tmin = 0.0f;          // TMin 0.0, TMax 10000 (PathTracing.hlsl:59-61)
-            r.dx = d.x; r.dy = d.y; r.dz = d.z; r.tmax = 10000.0f;
-          } else {
-            const float4 ro = ld_stream(ray_o + (size_t)ray_i * stride), rd = ld_stream(ray_d + (size_t)ray_i * stride);
-            r.ox = ro.x; r.oy = ro.y; r.oz = ro.z; r.tmin = ro.w;
-            r.dx = rd.x; r.dy = rd.y; r.dz = rd.z; r.tmax = rd.w;
-          }
-          // A ray with a NaN/Inf component can hit nothing (every comparison of the triangle test fails), but fmin/fmax
-          // drop NaNs, so its box tests would all pass and it would walk the whole BVH: report the miss right away.
-          const float chk = (r.ox + r.oy + r.oz) + (r.dx + r.dy + r.dz);
-          if (isfinite(chk)) {
-            tr.init(r, scene_mag);
-#ifdef PT_EXP_EXTRA_REFILL_VALU   // experiment: N more vector instructions per refilled ray: what does the refill path cost?
-            {
-              float d = r.ox;
-#pragma unroll
-              for (int k = 0; k < PT_EXP_EXTRA_REFILL_VALU; ++k) asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(d));
-              asm volatile("" ::"v"(d));
-            }
-#endif
-            busy = true;
-          } else {
-            hits[ray_i] = make_float4(-1.0f, 0.0f, 0.0f, __uint_as_float(0xFFFFFFFFu));
-          }
-        }
-        pool_next += take;
-      }
-      wave_risky = __ballot(busy && tr.risky) != 0ull;
-      if (__ballot(busy) == 0ull) continue;   // nothing to do yet (pool was empty): claim again or finish
-    }
-
-    // ---- one traversal iteration for the busy lanes ----
-    const uint32_t n_busy = (uint32_t)__popcll(__ballot(busy));
-    if (COUNT && __ballot(busy && tr.has_node_work()) != 0ull) ++n_node_steps;
-    if (!DEFER) {
-      if (busy) {
-        if (tr.has_node_work()) {
-          tr.node_step(nodes, stk, wave_risky, s_top, top_nodes);
-          if (COUNT) ++n_nodes;
-        } else {
-          tr.tg = tr.ng;
-          tr.ng = make_uint2(0u, 0u);
-        }
-      }
-      for (;;) {
-        const bool has = busy && tr.tg.y != 0u;
-        const unsigned long long m = __ballot(has);
-        if (m == 0ull) break;
-        if ((uint32_t)__popcll(m) * 100u < n_busy * postpone_pct) {
-          if (has) { stk.put(tr.sp, tr.tg); ++tr.sp; tr.tg.y = 0u; }   // postpone: too few lanes have triangle work
-          break;
-        }
-        if (COUNT) ++n_tri_steps;
-        if (has) {
-          const uint32_t nt = tr.template tri_step<PAIRS>(tris);
-          if (COUNT) n_tris += nt;
-        }
-      }
-      if (any_hit && busy && tr.best.prim != 0xFFFFFFFFu) { tr.ng.y = 0u; tr.tg.y = 0u; tr.sp = 0; }
-      if (busy && !tr.has_node_work()) {
-        if (tr.sp == 0) {
-          busy = false;
-          unsaved = true;
-        } else {
-          --tr.sp;
-          tr.ng = stk.get(tr.sp);
-        }
-      }
-    } else {
-      // Deferred-triangle schedule: triangle groups never go on the traversal stack. A lane parks them in its small
-      // queue and keeps doing box tests; the wave runs a triangle phase only when enough lanes have parked work
-      // (or a queue is full), so both phases run with most lanes active.
-      if (busy && tr.has_node_work()) {
-        tr.node_step(nodes, stk, wave_risky, s_top, top_nodes);
-        if (COUNT) ++n_nodes;
-      }
-      // Further node steps in the same iteration when no lane has to flush its queue: the previous step's triangle group
-      // is parked, lanes that ran out of node work pop their stack, and the scheduling decisions below (ballots, triangle
-      // phase, refill check) run once per PT_EXTEND_NODE_STEPS box tests. (Written out, not as a loop: the loop form costs
-      // 12 VGPRs and a resident wave per SIMD.)
-#define PT_EXTRA_NODE_STEP()                                                                                  \
-      if (__ballot(busy && tr.tg.y != 0u && dqn == dq_entries) == 0ull) {                                       \
-        if (busy && tr.tg.y != 0u) { dq[dqn * 64u] = tr.tg; ++dqn; tr.tg.y = 0u; }                              \
-        if (busy && !tr.has_node_work() && tr.sp != 0) { --tr.sp; tr.ng = stk.get(tr.sp); }                     \
-        if (COUNT && __ballot(busy && tr.has_node_work()) != 0ull) ++n_node_steps;                              \
-        if (busy && tr.has_node_work()) {                                                                       \
-          tr.node_step(nodes, stk, wave_risky, s_top, top_nodes);                                               \
-          if (COUNT) ++n_nodes;                                                                                 \
-        }                                                                                                       \
-      }
-#if PT_EXTEND_NODE_STEPS >= 2
-      PT_EXTRA_NODE_STEP()
-#endif
-#if PT_EXTEND_NODE_STEPS >= 3
-      PT_EXTRA_NODE_STEP()
-#endif
-#if PT_EXTEND_NODE_STEPS >= 4
-      PT_EXTRA_NODE_STEP()
-#endif
-#undef PT_EXTRA_NODE_STEP
-      const bool pending = busy && (tr.tg.y != 0u || dqn != 0u);
-      const unsigned long long pm = __ballot(pending);
-      if (pm != 0ull) {
-        const unsigned long long full = __ballot(busy && tr.tg.y != 0u && dqn == dq_entries);
-        if (full != 0ull || (uint32_t)__popcll(pm) * 100u >= n_busy * postpone_pct) {
-          for (;;) {
-            if (busy && tr.tg.y == 0u && dqn != 0u) { --dqn; tr.tg = dq[dqn * 64u]; }
-            const bool has = busy && tr.tg.y != 0u;
-            const unsigned long long m = __ballot(has);
-            if (m == 0ull) break;
-            const unsigned long long must = __ballot(has && dqn == dq_entries);
-            if (must == 0ull && (uint32_t)__popcll(m) * 100u < n_busy * continue_pct) break;   // tail: leave the rest parked
-            if (COUNT) ++n_tri_steps;
-            if (has) {
-              const uint32_t nt = tr.template tri_step<PAIRS>(tris);
-              if (COUNT) n_tris += nt;
-            }
-            // A second record of the same group without another round of ballots (single-triangle records only: +0.7 % C2,
-            // +1 % C4; with pair records the second step carries up to two more tests and the idle lanes cost 1.5 % on C5).
-            if (!PAIRS) {
-              if (COUNT && __ballot(has && tr.tg.y != 0u) != 0ull) ++n_tri_steps;
-              if (has && tr.tg.y != 0u) {
-                const uint32_t nt = tr.template tri_step<PAIRS>(tris);
-                if (COUNT) n_tris += nt;
-              }
-            }
-          }
-        }
-        if (busy && tr.tg.y != 0u) { dq[dqn * 64u] = tr.tg; ++dqn; tr.tg.y = 0u; }   // park what is left (room is guaranteed)
-      }
-      if (any_hit && busy && tr.best.prim != 0xFFFFFFFFu) { tr.ng.y = 0u; tr.tg.y = 0u; tr.sp = 0; dqn = 0u; }
-      if (busy && !tr.has_node_work()) {
-        if (tr.sp != 0) {
-          --tr.sp;
-          tr.ng = stk.get(tr.sp);
-        } else if (dqn == 0u) {
-          busy = false;
-          unsaved = true;
-        }   // else: only parked triangles left — wait for the wave's next triangle phase
-      }
-    }
-  }
-  if (unsaved) {   // rays that finished after the last refill
-    HitRec hr = tr.best;
-    if (hr.prim == 0xFFFFFFFFu) hr.t = -1.0f;
-    st_stream(hits + ray_i, make_float4(hr.t, hr.u, hr.v, __uint_as_float(hr.prim)));
-  }
-  if (COUNT) {
-    atomicAdd(&stats[ST_NODES], (unsigned long long)n_nodes);
-    atomicAdd(&stats[ST_TRIS], (unsigned long long)n_tris);
-    if (lane == 0u) {
-      atomicAdd(&stats[ST_NODE_WAVE_STEPS], (unsigned long long)n_node_steps);
-      atomicAdd(&stats[ST_TRI_WAVE_STEPS], (unsigned long long)n_tri_steps);
-    }
-  }
-}
+#define PT_EXTEND_NAME k_extend
+#define PT_EXTEND_ATTR __attribute__((amdgpu_waves_per_eu(PT_EXTEND_WAVES_PER_EU, PT_EXTEND_WAVES_PER_EU)))
+#include "extend_kernel.inc"
+#undef PT_EXTEND_NAME
+#undef PT_EXTEND_ATTR
+// The same traversal with the register allocation left alone: no private segment, so a launch can never make the
+// runtime allocate one. For pt_trace_rays_device_noalloc (callers that must not allocate).
+#define PT_EXTEND_NAME k_extend_ns
+#define PT_EXTEND_ATTR
+#include "extend_kernel.inc"
+#undef PT_EXTEND_NAME
+#undef PT_EXTEND_ATTR
 
 // ------------------------------------------------------------------------------------------------ extend, coherent packets
 // Primary rays of a fused batch arrive as 8x8-pixel tiles (PrimaryRayOfSlot): the 64 rays of a wave share almost their
@@ -1140,9 +890,16 @@ size_t extend_lds_bytes(uint32_t lds_entries_total, uint32_t top_nodes) {
   return (size_t)lds_entries_total * 64u * sizeof(uint2) * 4u + (size_t)top_nodes * PT_NODE_STRIDE_U4 * 16u;
 }
 
-int extend_occupancy_blocks(uint32_t lds_entries_total, uint32_t top_nodes, bool defer, bool paired) {
+int extend_occupancy_blocks(uint32_t lds_entries_total, uint32_t top_nodes, bool defer, bool paired, bool no_private_segment) {
   int nb = 0;
   const size_t lds = extend_lds_bytes(lds_entries_total, top_nodes);
+  if (no_private_segment) {
+    const hipError_t e = paired ? (defer ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_extend_ns<false, true, true>, 256, lds)
+                                         : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_extend_ns<false, false, true>, 256, lds))
+                                : (defer ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_extend_ns<false, true, false>, 256, lds)
+                                         : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_extend_ns<false, false, false>, 256, lds));
+    return (e != hipSuccess || nb < 1) ? 1 : nb;
+  }
   // per instantiation: the pair test holds one more vertex in registers (5 waves per SIMD instead of 6)
   const hipError_t e = paired ? (defer ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_extend<false, true, true>, 256, lds)
                                        : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_extend<false, false, true>, 256, lds))
@@ -1174,7 +931,20 @@ void launch_extend(const DeviceScene& sc, const float4* ray_o, const float4* ray
   hipLaunchKernelGGL((k_extend<C, D, P>), dim3(cfg.extend_blocks), dim3(256), lds, s, sc.nodes, sc.tris, ray_o, ray_d, hits, count, \
                      work_cursor, stats, lds_entries, spill_entries, sc.spill, stride, cfg.fetch_min, cfg.postpone_pct, dq, any_hit ? 1u : 0u, sc.scene_mag, top_nodes, cfg.continue_pct, primary_gen)
 #define PT_LAUNCH_EXTEND2(C, D) do { if (sc.paired) PT_LAUNCH_EXTEND(C, D, true); else PT_LAUNCH_EXTEND(C, D, false); } while (0)
-  if (dq > 0) {
+  if (cfg.no_private_segment) {   // pt_trace_rays_device_noalloc: the instantiations that use no scratch memory (never the counting ones)
+#define PT_LAUNCH_EXTEND_NS(D, P)                                                                                            \
+  hipLaunchKernelGGL((k_extend_ns<false, D, P>), dim3(cfg.extend_blocks), dim3(256), lds, s, sc.nodes, sc.tris, ray_o, ray_d, hits, count, \
+                     work_cursor, stats, lds_entries, spill_entries, sc.spill, stride, cfg.fetch_min, cfg.postpone_pct, dq, any_hit ? 1u : 0u, sc.scene_mag, top_nodes, cfg.continue_pct, primary_gen)
+    if (lds > 64 * 1024) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_extend_ns<false, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_extend_ns<false, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_extend_ns<false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_extend_ns<false, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    }
+    if (dq > 0) { if (sc.paired) PT_LAUNCH_EXTEND_NS(true, true); else PT_LAUNCH_EXTEND_NS(true, false); }
+    else { if (sc.paired) PT_LAUNCH_EXTEND_NS(false, true); else PT_LAUNCH_EXTEND_NS(false, false); }
+#undef PT_LAUNCH_EXTEND_NS
+  } else if (dq > 0) {
     if (count_traversal) PT_LAUNCH_EXTEND2(true, true); else PT_LAUNCH_EXTEND2(false, true);
   } else {
     if (count_traversal) PT_LAUNCH_EXTEND2(true, false); else PT_LAUNCH_EXTEND2(false, false);

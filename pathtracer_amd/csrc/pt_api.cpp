@@ -69,6 +69,7 @@ struct pt_ctx {
   bool pipeline = false;
   bool fused_primary = PT_DEFAULT_FUSED_PRIMARY != 0;   // PT_OPT_FUSED_PRIMARY
   bool primary_packet = true;         // PT_OPT_PRIMARY_PACKET: fused primaries traced by k_extend_packet (one BVH walk per wave)
+  int noalloc_blocks = 0;             // grid of pt_trace_rays_device_noalloc's extend instantiation (extend_grid)
   int packet_blocks = 0;              // its persistent grid (CUs x occupancy), looked up on first use per scene
   bool last_render_fused = false;     // the bounce-0 queue of the last pt_render was never written (pt_debug_read_queue)
   float4* ao_o = nullptr;       // AO pipeline: 16 rays per pixel-sample (origin,tmin / dir,tmax / hit records)
@@ -93,6 +94,7 @@ struct pt_ctx {
   double extend_ms = 0.0, render_ms = 0.0;
   double extend_ms_bounce[16] = {0};
   uint64_t extend_launches = 0;
+  uint64_t extend_launches_bounce[16] = {0};
 
   int fail(int code, const std::string& msg) {
     err = msg;
@@ -224,6 +226,12 @@ int ensure_tmp(pt_ctx* ctx, uint64_t rays) {
 
 // Persistent grid of the extend kernel: CUs x resident blocks of the instantiation that will be launched.
 int extend_grid(pt_ctx* ctx) {
+  {   // the grid of pt_trace_rays_device_noalloc's instantiation (no private segment, its own register count), so that
+      // entry point has nothing to look up
+    const uint32_t le = std::min<uint32_t>(std::min(ctx->ds.stack_entries, ctx->cfg.lds_stack_entries) + ctx->cfg.defer_entries, PT_EXTEND_MAX_LDS_ENTRIES);
+    ctx->noalloc_blocks = ctx->cfg.num_cus * std::max(1, std::min(8, extend_occupancy_blocks(le, std::min<uint32_t>(ctx->cfg.top_nodes, ctx->ds.num_nodes),
+                                                                                             ctx->cfg.defer_entries > 0, ctx->ds.paired, true)));
+  }
   int per_cu = ctx->cfg.extend_blocks_per_cu;
   if (per_cu <= 0) {
     const uint32_t lds_entries = std::min<uint32_t>(std::min(ctx->ds.stack_entries, ctx->cfg.lds_stack_entries) + ctx->cfg.defer_entries, PT_EXTEND_MAX_LDS_ENTRIES);
@@ -283,6 +291,7 @@ void extend_one(pt_ctx* ctx, const float4* ro, const float4* rd, uint32_t stride
     launch_extend(ctx->ds, ro, rd, stride, hits, count, cursor, ctx->wb.stats, ctx->count_traversal, any_hit, ctx->cfg, st, primary_gen);
   }
   ctx->extend_launches++;
+  ctx->extend_launches_bounce[std::min(15, std::max(0, bounce))]++;
   if (ctx->time_kernels) {
     (void)hipEventRecord(ev.second, st);
     ctx->extend_events.push_back(ev);
@@ -904,6 +913,10 @@ int pt_trace_rays_device_noalloc(pt_ctx* ctx, const PtRay* device_rays, uint64_t
   // The spill region of the per-lane stacks comes out of the static scratch, so the persistent grid is cut to the
   // waves it has room for; a BVH so deep that not even one block per CU fits is rejected.
   LaunchCfg cfg = ctx->cfg;
+  // k_extend pins its register budget and spills a few registers to the private segment, which the runtime allocates
+  // on demand; this entry point launches the instantiation that has none (one wave per SIMD less), on its own grid
+  cfg.no_private_segment = true;
+  if (ctx->noalloc_blocks > 0) cfg.extend_blocks = std::min(cfg.extend_blocks, ctx->noalloc_blocks);   // never beyond the spill region sized for cfg.extend_blocks
   const uint32_t lds_entries = std::min<uint32_t>(std::min(ctx->ds.stack_entries, cfg.lds_stack_entries), PT_EXTEND_MAX_LDS_ENTRIES - cfg.defer_entries);
   const uint64_t spill_bytes_per_wave = (uint64_t)(ctx->ds.stack_entries - lds_entries) * 64u * sizeof(uint2);
   if (spill_bytes_per_wave) {
@@ -1061,6 +1074,7 @@ int pt_stats_get(pt_ctx* ctx, PtStats* out) {
   }
   for (int b = 0; b < 16; ++b) out->extend_ms_bounce[b] = ctx->extend_ms_bounce[b];
   out->extend_launches = ctx->extend_launches;
+  for (int b = 0; b < 16; ++b) out->extend_launches_bounce[b] = ctx->extend_launches_bounce[b];
   out->extend_ms = ctx->extend_ms;
   out->render_ms = ctx->render_ms;
   return PT_OK;
@@ -1073,6 +1087,7 @@ int pt_stats_reset(pt_ctx* ctx) {
   ctx->extend_ms = 0.0;
   ctx->render_ms = 0.0;
   ctx->extend_launches = 0;
+  for (int b = 0; b < 16; ++b) ctx->extend_launches_bounce[b] = 0;
   for (int b = 0; b < 16; ++b) ctx->extend_ms_bounce[b] = 0.0;
   if (ctx->wb.stats) PT_HIP(hipMemset(ctx->wb.stats, 0, ST_WORDS * sizeof(unsigned long long)));
   if (ctx->wb2.stats) PT_HIP(hipMemset(ctx->wb2.stats, 0, ST_WORDS * sizeof(unsigned long long)));

@@ -1104,6 +1104,39 @@ def test_fused_primary_rays_are_bit_identical_to_the_generate_pass(ctx, oracle, 
         assert np.array_equal(v[0].view(np.uint32), ref[0].view(np.uint32)), k
 
 
+@pytest.mark.parametrize("pairs", [False, True], ids=["48-byte-triangles", "64-byte-pairs"])
+@pytest.mark.parametrize("size", [(200, 120), (204, 118), (64, 8)])
+def test_packet_kernel_for_primaries_is_bit_identical_to_the_per_lane_traversal(ctx, oracle, pairs, size):
+    """PT_OPT_PRIMARY_PACKET (default 1): the fused primaries are traced by k_extend_packet, one BVH walk per wave with
+    wave-uniform node / triangle fetches, instead of k_extend's walk per lane. The triangle test and the closest-hit rule
+    are the same, so target sums, ray counts and the bounce-1 queue's content must not change by a bit: tiled and
+    row-ordered frames (coherent and mixed-octant waves: the camera looks along an axis, so the image centre splits
+    octants), both leaf-record formats, and a camera far outside the scene whose rays mostly miss."""
+    ctx.scene_create(scenes.atrium(1), api.PT_SCENE_PAIR_TRIANGLES if pairs else api.PT_SCENE_NO_PAIRS)
+    ctx.sky_set(oracle.earth_atmosphere())
+    (w, h), spp = size, 3
+    cams = [scenes.ATRIUM_CAM, {"eye": (0.0, 60.0, -90.0), "target": (0.0, 4.0, 0.0)}, {"eye": (1.0, 1.7, 0.5), "target": (1.0, 1.7, 9.0)}]
+    try:
+        for cam in cams:
+            c = lookat_consts(w, h, cam, depth=2)
+            out = {}
+            for packet in (0, 1):
+                ctx.set_option(api.PT_OPT_PRIMARY_PACKET, packet)
+                ctx.accum_reset(w, h)
+                ctx.stats_reset()
+                ctx.render(c, w, h, 5, spp)
+                st = ctx.stats()
+                q1 = ctx.debug_read_queue(1)
+                key = np.sort(q1.view(np.uint32).reshape(len(q1), 8), axis=0)      # queue order depends on block scheduling
+                out[packet] = (ctx.accum_read_sum()[0].copy(), (st.rays, st.shaded_hits, st.sky_misses, tuple(st.rays_bounce)), key)
+            assert out[0][1] == out[1][1], cam
+            assert np.array_equal(out[0][0].view(np.uint32), out[1][0].view(np.uint32)), cam
+            assert np.array_equal(out[0][2], out[1][2]), cam
+            assert out[1][1][0] > w * h * spp                                       # some secondary rays exist
+    finally:
+        ctx.set_option(api.PT_OPT_PRIMARY_PACKET, 1)
+
+
 # ---------------------------------------------------------------------------------------------- API behaviour
 def test_default_batch_shrinks_when_device_memory_is_short():
     """The default wavefront batch is 2^27 paths (20 GB). When that much device memory is not free, pt_render halves the

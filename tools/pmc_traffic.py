@@ -31,7 +31,7 @@ out["extend_valu_wave_instr_per_launch"] = e["valu_wave_instr_per_launch"] if e 
 out["extend_lanes_active_per_valu_instr"] = e["lanes_active_per_valu_instr"] if e else None
 # vector-memory pipe of the extend kernel: TA / TD busy cycles (summed over the 256 CUs) against the dispatch's cycles
 # (GRBM_GUI_ACTIVE is summed over the 8 XCDs), wave-level load instructions per launch
-ke = next((k for k in acc if k.startswith("pt::k_extend")), None)
+ke = "pt::k_extend" if "pt::k_extend" in acc else None   # not k_extend_packet (the coherent primaries): that has its own entry under "kernels"
 if ke and acc[ke].get("GRBM_GUI_ACTIVE") and acc[ke].get("TA_TA_BUSY_sum"):
     cyc = acc[ke]["GRBM_GUI_ACTIVE"] / calls[ke]["GRBM_GUI_ACTIVE"] / 8.0
     out["extend_cycles_per_launch"] = round(cyc)
