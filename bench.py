@@ -71,8 +71,9 @@ def main():
     ap.add_argument("--pipeline", type=int, default=0, choices=[0, 1],
                     help="1 = two pipeline lanes per batch (PT_OPT_PIPELINE): higher throughput, but extend launches then "
                          "overlap other kernels and the per-launch durations of the roofline grow")
-    ap.add_argument("--primary-packet", type=int, default=1, choices=[0, 1],
-                    help="PT_OPT_PRIMARY_PACKET: 1 (library default) = the coherent primaries are traced by k_extend_packet, 0 = by k_extend")
+    ap.add_argument("--primary-packet", type=int, default=2, choices=[0, 1, 2],
+                    help="PT_OPT_PRIMARY_PACKET: 0 = the primaries are traced by k_extend, 1 = by k_extend_packet, 2 (library default) = "
+                         "by whichever the library times faster on this scene and frame size")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
@@ -183,6 +184,7 @@ def main():
     barrier()
     t1 = time.perf_counter()
     st = ctx.stats()
+    used_packet = st.packet_launches > 0   # bounce 0 went through k_extend_packet (PT_OPT_PRIMARY_PACKET, library's choice at 2)
     elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
     counts = torch.tensor([st.rays, st.samples], dtype=torch.float64, device=dev)
     if world > 1:
@@ -215,7 +217,7 @@ def main():
         ship = count_pass(DEF_DEFER, DEF_POSTPONE)
         cn, ct, cr = sc_.nodes_visited, sc_.tris_tested, sc_.rays
         sn, st_, sr, snw, stw = ship.nodes_visited, ship.tris_tested, ship.rays, ship.node_wave_steps, ship.tri_wave_steps
-        if args.primary_packet and depth > 0:
+        if used_packet and depth > 0:
             # bounce 0 belongs to k_extend_packet: k_extend's per-ray figures are those of the secondary bounces (same samples
             # traced to depth 0, subtracted)
             p0, p1 = count_pass(0, 0, True), count_pass(DEF_DEFER, DEF_POSTPONE, True)
@@ -245,7 +247,7 @@ def main():
         except (OSError, ValueError, KeyError):
             pass
         # k_extend's launches: every bounce, or bounces >= 1 when the fused primaries went through k_extend_packet
-        packet = bool(args.primary_packet) and se.extend_launches_bounce[0] > 0
+        packet = se.packet_launches > 0
         b_from = 1 if packet else 0
         k_launches = max(1, sum(se.extend_launches_bounce[b_from:]))
         k_ms = sum(se.extend_ms_bounce[b_from:])
@@ -310,6 +312,8 @@ def main():
                                 "mrays_per_s": round(se.rays_bounce[0] / max(se.extend_ms_bounce[0], 1e-9) / 1e3, 1),
                                 "note": "bounce 0 (coherent 8x8-pixel tiles): one BVH walk per wave, scalar node / triangle fetches"}
                                if packet else None),
+            "primary_kernel_choice": {"option": args.primary_packet, "timed_ms_k_extend": round(se.packet_cal_ms[0], 4),
+                                      "timed_ms_k_extend_packet": round(se.packet_cal_ms[1], 4)},
             "bytes_per_launch": round(alg_bytes, 1),
             "extend_share_of_render": round(se.extend_ms / max(se.render_ms, 1e-9), 4),
             "extend_mrays_per_s": round(se.rays / max(ext_s, 1e-12) / 1e6, 2),

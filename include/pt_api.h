@@ -173,7 +173,9 @@ typedef struct PtStats {
   double extend_ms_bounce[16];   /* extend-kernel time at bounce b (only when timing is on) */
   uint64_t node_wave_steps;      /* wave-level node steps (counting on): nodes_visited / (64*this) = lane utilisation */
   uint64_t tri_wave_steps;       /* wave-level triangle steps (counting on) */
-  uint64_t extend_launches_bounce[16]; /* traversal-kernel launches at bounce b (bounce 0 of a fused pt_render: k_extend_packet) */
+  uint64_t extend_launches_bounce[16]; /* traversal-kernel launches at bounce b */
+  uint64_t packet_launches;      /* of those, launches of k_extend_packet (the coherent-primaries kernel, PT_OPT_PRIMARY_PACKET) */
+  float packet_cal_ms[2];        /* PT_OPT_PRIMARY_PACKET = 2: what the one-off timing measured on <= 2^24 primaries: k_extend, k_extend_packet */
 } PtStats;
 
 typedef struct PtSceneInfo {
@@ -210,8 +212,10 @@ enum {
   PT_OPT_FUSED_PRIMARY = 14,       /* 0/1 (default 1): pt_render computes primary rays inside the traversal and shading kernels
                                       (RayGen's ray set-up, PathTracing.hlsl:40-61) instead of writing them to the bounce-0 queue
                                       and reading them back: 160 B of memory traffic per path less, results bit-identical */
-  PT_OPT_PRIMARY_PACKET = 15,      /* 0/1 (default 1): the fused primaries of pt_render (coherent 8x8-pixel tiles) are traced by one BVH walk
-                                      per wave with wave-uniform node fetches; 0 = by the general per-lane traversal kernel. Same hit records. */
+  PT_OPT_PRIMARY_PACKET = 15,      /* which kernel traces the fused primaries of pt_render (coherent 8x8-pixel tiles): 0 = the general per-lane
+                                      traversal, 1 = one BVH walk per wave with wave-uniform node fetches (k_extend_packet), 2 (default) = the
+                                      faster of the two, timed once per scene and frame size on <= 2^24 primaries (one stream
+                                      synchronisation inside that pt_render call). Same hit records either way. */
   PT_OPT_PIPELINE = 11             /* 0/1 (default 0): split every batch of >= 2 samples into two halves that run on two streams (the
                                       second one internal): one half's shade kernels and kernel drains run under the other half's
                                       extend, +2..5 % throughput, results bit-identical; off by default because concurrent kernels

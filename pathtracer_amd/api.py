@@ -124,7 +124,7 @@ class PtStats(C.Structure):
                 ("extend_ms", C.c_double), ("render_ms", C.c_double),
                 ("rays_bounce", C.c_uint64 * 16), ("extend_ms_bounce", C.c_double * 16),
                 ("node_wave_steps", C.c_uint64), ("tri_wave_steps", C.c_uint64),
-                ("extend_launches_bounce", C.c_uint64 * 16)]
+                ("extend_launches_bounce", C.c_uint64 * 16), ("packet_launches", C.c_uint64), ("packet_cal_ms", C.c_float * 2)]
 
 
 class PtSceneInfo(C.Structure):

@@ -68,7 +68,12 @@ struct pt_ctx {
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   bool pipeline = false;
   bool fused_primary = PT_DEFAULT_FUSED_PRIMARY != 0;   // PT_OPT_FUSED_PRIMARY
-  bool primary_packet = true;         // PT_OPT_PRIMARY_PACKET: fused primaries traced by k_extend_packet (one BVH walk per wave)
+  int primary_packet = 2;             // PT_OPT_PRIMARY_PACKET: 0 = k_extend, 1 = k_extend_packet (one BVH walk per wave), 2 = whichever is
+                                      // faster on this scene at this frame size (timed once, calibrate_primary_kernel)
+  int packet_choice = -1;             // the outcome of that timing (-1 = not timed yet), for packet_choice_w x packet_choice_h
+  uint32_t packet_choice_w = 0, packet_choice_h = 0;
+  float packet_cal_ms[2] = {0.0f, 0.0f};   // what it measured: k_extend, k_extend_packet
+  uint64_t packet_launches = 0;
   int noalloc_blocks = 0;             // grid of pt_trace_rays_device_noalloc's extend instantiation (extend_grid)
   int packet_blocks = 0;              // its persistent grid (CUs x occupancy), looked up on first use per scene
   bool last_render_fused = false;     // the bounce-0 queue of the last pt_render was never written (pt_debug_read_queue)
@@ -283,6 +288,7 @@ void extend_one(pt_ctx* ctx, const float4* ro, const float4* rd, uint32_t stride
     if (ctx->packet_blocks <= 0)
       ctx->packet_blocks = ctx->cfg.num_cus * std::max(1, std::min(8, extend_packet_occupancy_blocks(ctx->ds.stack_entries, ctx->ds.paired)));
     launch_extend_packet(ctx->ds, ro, rd, hits, count, cursor, ctx->packet_blocks, st, primary_gen);
+    ctx->packet_launches++;
   } else if (lane) {
     DeviceScene ds2 = ctx->ds;
     ds2.spill = ctx->spill2;
@@ -297,6 +303,44 @@ void extend_one(pt_ctx* ctx, const float4* ro, const float4* rd, uint32_t stride
     ctx->extend_events.push_back(ev);
     ctx->extend_event_bounce.push_back(bounce);
   }
+}
+
+// PT_OPT_PRIMARY_PACKET = 2: which kernel traces the fused primaries of this scene at this frame size faster? The wave-level
+// walk of k_extend_packet wins while the 64 rays of an 8x8-pixel tile share most of their path (atrium at 1080p: 11.2 vs
+// 8.1 Grays/s; courtyard at 4K: +12 %) and loses once the triangles are small against a tile's footprint (street at 1080p:
+// 6.7 vs 8.3). Both produce the same hit records, so the choice is made by timing them once on up to 2^24 primaries of the
+// frame about to be rendered (HIP events, one synchronisation per scene and frame size); the hit records this leaves in the
+// first lane's buffers are overwritten by the render itself.
+int calibrate_primary_kernel(pt_ctx* ctx, const PtRtConsts& consts, uint32_t width, uint32_t height, uint32_t first_sample, uint32_t k) {
+  WavefrontBuffers& wb = ctx->wb;
+  const uint64_t n_paths = (uint64_t)width * height * k;
+  const uint32_t n_cal = (uint32_t)std::min<uint64_t>(n_paths, 1ull << 24);   // large enough for the work-claim chunks of a real batch
+  uint32_t* count = wb.counters + CTR_AT(CTR_QCOUNT0 + 63);   // bounce slot 63 is never a real bounce (myMaxRecursionDepth <= 62)
+  uint32_t* cursor = wb.counters + CTR_AT(CTR_WORK0 + 63);
+  PT_HIP(hipMemsetAsync(wb.counters, 0, CTR_WORDS * sizeof(uint32_t), ctx->stream));
+  launch_primary_setup(consts, wb, width, height, first_sample, k, ctx->stream);
+  launch_set_count(count, n_cal, ctx->stream);
+  if (ctx->packet_blocks <= 0)
+    ctx->packet_blocks = ctx->cfg.num_cus * std::max(1, std::min(8, extend_packet_occupancy_blocks(ctx->ds.stack_entries, ctx->ds.paired)));
+  std::pair<hipEvent_t, hipEvent_t> ev[2] = {get_event_pair(ctx), get_event_pair(ctx)};
+  for (int pass = 0; pass < 3; ++pass) {   // packet (untimed: warms the caches and loads both code objects' neighbours), k_extend, packet
+    const int which = pass == 1 ? 0 : 1;
+    PT_HIP(hipMemsetAsync(cursor, 0, sizeof(uint32_t), ctx->stream));
+    if (pass > 0) PT_HIP(hipEventRecord(ev[which].first, ctx->stream));
+    if (which) launch_extend_packet(ctx->ds, nullptr, nullptr, wb.hits, count, cursor, ctx->packet_blocks, ctx->stream, wb.gen);
+    else launch_extend(ctx->ds, nullptr, nullptr, 1, wb.hits, count, cursor, wb.stats, false, false, ctx->cfg, ctx->stream, wb.gen);
+    if (pass > 0) PT_HIP(hipEventRecord(ev[which].second, ctx->stream));
+  }
+  PT_HIP(hipEventSynchronize(ev[1].second));
+  for (int i = 0; i < 2; ++i) {
+    ctx->packet_cal_ms[i] = 0.0f;
+    PT_HIP(hipEventElapsedTime(&ctx->packet_cal_ms[i], ev[i].first, ev[i].second));
+    ctx->event_pool.push_back(ev[i]);
+  }
+  ctx->packet_choice = ctx->packet_cal_ms[1] <= ctx->packet_cal_ms[0] ? 1 : 0;
+  ctx->packet_choice_w = width;
+  ctx->packet_choice_h = height;
+  return PT_OK;
 }
 
 }  // namespace
@@ -417,7 +461,7 @@ int pt_set_option(pt_ctx* ctx, int option, int64_t value) {
       if (ctx->has_scene)
         ctx->cfg.extend_blocks = extend_grid(ctx);
       return PT_OK;
-    case PT_OPT_PRIMARY_PACKET: ctx->primary_packet = value != 0; return PT_OK;
+    case PT_OPT_PRIMARY_PACKET: ctx->primary_packet = value < 0 ? 0 : (value > 2 ? 2 : (int)value); return PT_OK;
     case PT_OPT_FUSED_PRIMARY:
       if (value != 0 && value != 1) return ctx->fail(PT_ERR_INVALID_ARG, "PT_OPT_FUSED_PRIMARY must be 0 or 1");
       ctx->fused_primary = value != 0;
@@ -562,6 +606,7 @@ int pt_scene_create(pt_ctx* ctx, const PtMeshDesc* meshes, uint32_t num_meshes, 
   in.build_ms = bvh.build_ms;
   ctx->has_scene = true;
   ctx->packet_blocks = 0;   // depends on the scene (stack depth, record format)
+  ctx->packet_choice = -1;
   return PT_OK;
 }
 
@@ -751,6 +796,14 @@ int pt_render(pt_ctx* ctx, const PtRtConsts* consts, uint32_t width, uint32_t he
   if (use_skyview) launch_skyview_lut(*consts, ctx->lut, ctx->skyview, ctx->stream);   // 64 Ki texels, a few microseconds
   const bool fused = ctx->fused_primary;   // primaries computed inside k_extend / k_shade instead of a k_generate pass
   ctx->last_render_fused = fused;
+  bool packet = fused && ctx->primary_packet == 1 && !ctx->count_traversal;
+  if (fused && ctx->primary_packet == 2 && !ctx->count_traversal) {
+    if (ctx->packet_choice < 0 || ctx->packet_choice_w != width || ctx->packet_choice_h != height) {
+      const uint32_t k0 = (uint32_t)std::min<uint64_t>(two_lanes && spb >= 2 ? (spb + 1) / 2 : spb, num_samples);
+      if ((rc = calibrate_primary_kernel(ctx, *consts, width, height, first_sample, std::max<uint32_t>(1u, k0))) != PT_OK) return rc;
+    }
+    packet = ctx->packet_choice == 1;
+  }
   for (uint32_t done = 0; done < num_samples;) {
     const uint32_t k = (uint32_t)std::min<uint64_t>(spb, num_samples - done);
     const uint32_t k_lane[2] = {two_lanes && k >= 2 ? (k + 1) / 2 : k, two_lanes && k >= 2 ? k / 2 : 0};
@@ -772,7 +825,7 @@ int pt_render(pt_ctx* ctx, const PtRtConsts* consts, uint32_t width, uint32_t he
       for (int l = 0; l < n_lanes; ++l) {
         WavefrontBuffers& wb = *wbs[l];
         extend_one(ctx, wb.ray_o[in], wb.ray_d[in], 1, wb.hits, wb.counters + CTR_AT(CTR_QCOUNT0 + b), wb.counters + CTR_AT(CTR_WORK0 + b), (int)b, false, l,
-                   (fused && b == 0) ? wb.gen : nullptr, /*packet=*/fused && b == 0 && ctx->primary_packet && !ctx->count_traversal);
+                   (fused && b == 0) ? wb.gen : nullptr, /*packet=*/packet && b == 0);
         launch_shade(*consts, ctx->ds, wb, (int)b, width, height, first_lane[l], wh * k_lane[l], ctx->russian_roulette, ctx->cfg, streams[l], fused);
       }
     }
@@ -1074,6 +1127,9 @@ int pt_stats_get(pt_ctx* ctx, PtStats* out) {
   }
   for (int b = 0; b < 16; ++b) out->extend_ms_bounce[b] = ctx->extend_ms_bounce[b];
   out->extend_launches = ctx->extend_launches;
+  out->packet_launches = ctx->packet_launches;
+  out->packet_cal_ms[0] = ctx->packet_cal_ms[0];
+  out->packet_cal_ms[1] = ctx->packet_cal_ms[1];
   for (int b = 0; b < 16; ++b) out->extend_launches_bounce[b] = ctx->extend_launches_bounce[b];
   out->extend_ms = ctx->extend_ms;
   out->render_ms = ctx->render_ms;
@@ -1087,6 +1143,7 @@ int pt_stats_reset(pt_ctx* ctx) {
   ctx->extend_ms = 0.0;
   ctx->render_ms = 0.0;
   ctx->extend_launches = 0;
+  ctx->packet_launches = 0;
   for (int b = 0; b < 16; ++b) ctx->extend_launches_bounce[b] = 0;
   for (int b = 0; b < 16; ++b) ctx->extend_ms_bounce[b] = 0.0;
   if (ctx->wb.stats) PT_HIP(hipMemset(ctx->wb.stats, 0, ST_WORDS * sizeof(unsigned long long)));

@@ -1120,7 +1120,7 @@ def test_packet_kernel_for_primaries_is_bit_identical_to_the_per_lane_traversal(
         for cam in cams:
             c = lookat_consts(w, h, cam, depth=2)
             out = {}
-            for packet in (0, 1):
+            for packet in (0, 1, 2):                                               # 2 = the library times both and picks
                 ctx.set_option(api.PT_OPT_PRIMARY_PACKET, packet)
                 ctx.accum_reset(w, h)
                 ctx.stats_reset()
@@ -1129,12 +1129,15 @@ def test_packet_kernel_for_primaries_is_bit_identical_to_the_per_lane_traversal(
                 q1 = ctx.debug_read_queue(1)
                 key = np.sort(q1.view(np.uint32).reshape(len(q1), 8), axis=0)      # queue order depends on block scheduling
                 out[packet] = (ctx.accum_read_sum()[0].copy(), (st.rays, st.shaded_hits, st.sky_misses, tuple(st.rays_bounce)), key)
-            assert out[0][1] == out[1][1], cam
-            assert np.array_equal(out[0][0].view(np.uint32), out[1][0].view(np.uint32)), cam
-            assert np.array_equal(out[0][2], out[1][2]), cam
+                assert (st.packet_launches > 0) == (packet == 1) or packet == 2
+            for packet in (1, 2):
+                assert out[0][1] == out[packet][1], cam
+                assert np.array_equal(out[0][0].view(np.uint32), out[packet][0].view(np.uint32)), cam
+                assert np.array_equal(out[0][2], out[packet][2]), cam
             assert out[1][1][0] > w * h * spp                                       # some secondary rays exist
+        assert min(ctx.stats().packet_cal_ms) > 0.0                                 # the automatic mode did time both kernels
     finally:
-        ctx.set_option(api.PT_OPT_PRIMARY_PACKET, 1)
+        ctx.set_option(api.PT_OPT_PRIMARY_PACKET, 2)
 
 
 # ---------------------------------------------------------------------------------------------- API behaviour
