@@ -134,7 +134,7 @@ __global__ void __launch_bounds__(256) k_generate(PtRtConsts c, float4* __restri
   if (p >= n_paths) return;
   PrimaryFrame f;
   f.corner = ld3(c.myNearPlaneCorner); f.xAxis = ld3(c.myXAxis); f.yAxis = ld3(c.myYAxis); f.camPos = ld3(c.myCameraPos);
-  f.w = w; f.h = h; f.wh = w * h; f.first_sample = first_sample;
+  f.w = w; f.h = h; f.wh = w * h; f.first_sample = first_sample; f.k = n_paths / (w * h);
   v3 o, d;
   const uint32_t rng_w = PrimaryRayOfPath(p, f, o, d);
   ray_o[p] = make_float4(o.x, o.y, o.z, 0.0f);       // TMin 0.0   (:59)
@@ -154,6 +154,7 @@ __global__ void k_primary_setup(PtRtConsts c, float4* __restrict__ gen, uint32_t
   gen[1] = make_float4(c.myXAxis[0], c.myXAxis[1], c.myXAxis[2], __uint_as_float(h));
   gen[2] = make_float4(c.myYAxis[0], c.myYAxis[1], c.myYAxis[2], __uint_as_float(w * h));
   gen[3] = make_float4(c.myCameraPos[0], c.myCameraPos[1], c.myCameraPos[2], __uint_as_float(first_sample));
+  gen[4] = make_float4(__uint_as_float(n_paths / (w * h)), 0.0f, 0.0f, 0.0f);   // samples per pixel of the batch (path ids are pixel-major)
   counters[CTR_AT(CTR_QCOUNT0)] = n_paths;
 }
 
@@ -288,6 +289,7 @@ __global__ void __launch_bounds__(256) k_extend_packet(const uint4* __restrict__
     const float4 g0 = gen[0], g1 = gen[1], g2 = gen[2], g3 = gen[3];
     f.corner = mk3(g0.x, g0.y, g0.z); f.xAxis = mk3(g1.x, g1.y, g1.z); f.yAxis = mk3(g2.x, g2.y, g2.z); f.camPos = mk3(g3.x, g3.y, g3.z);
     f.w = __float_as_uint(g0.w); f.h = __float_as_uint(g1.w); f.wh = __float_as_uint(g2.w); f.first_sample = __float_as_uint(g3.w);
+    f.k = __float_as_uint(gen[4].x);
   }
   for (;;) {
     uint32_t base = 0u;
@@ -452,7 +454,8 @@ __global__ void __launch_bounds__(PT_SHADE_THREADS, PT_SHADE_MIN_WAVES) k_shade(
                                                float4* __restrict__ ray_d_out, uint32_t* __restrict__ qid_out,
                                                float4* __restrict__ sky_o, float4* __restrict__ sky_d,
                                                uint32_t* __restrict__ counters, int bounce, uint32_t w, uint32_t h,
-                                               uint32_t first_sample, uint32_t russian_roulette) {
+                                               uint32_t first_sample, uint32_t russian_roulette, uint32_t spp) {
+  // spp: samples per pixel of the batch (path id = pixel * spp + sample)
   // FUSED (only at bounce 0): no k_generate ran; the ray is recomputed from the path index, T = 1, L = 0 and the
   // RNG counter after the jitter are constants, and this kernel (k_sky for sky misses) gives st_L its first value
   const uint32_t n = counters[CTR_AT(CTR_QCOUNT0 + bounce)];
@@ -461,10 +464,10 @@ __global__ void __launch_bounds__(PT_SHADE_THREADS, PT_SHADE_MIN_WAVES) k_shade(
   const bool last_bounce = (uint32_t)bounce >= c.myMaxRecursionDepth;
   const uint32_t wh = w * h;
   uint32_t shaded_local = 0u, miss_local = 0u;
-  const FastDiv div_wh(wh, 0x7fffffffu), div_w(w, wh);   // path ids stay below 2^31 (pt_api.cpp batch sizing)
+  const FastDiv div_w(w, wh);   // path ids stay below 2^31 (pt_api.cpp batch sizing)
   PrimaryFrame pf;
   pf.corner = ld3(c.myNearPlaneCorner); pf.xAxis = ld3(c.myXAxis); pf.yAxis = ld3(c.myYAxis); pf.camPos = ld3(c.myCameraPos);
-  pf.w = w; pf.h = h; pf.wh = wh; pf.first_sample = first_sample;
+  pf.w = w; pf.h = h; pf.wh = wh; pf.first_sample = first_sample; pf.k = spp;
   int parity = 0;
   for (uint32_t j0 = blockIdx.x * blockDim.x; j0 < n; j0 += gridDim.x * blockDim.x, parity ^= 1) {  // block-uniform trip count
     const uint32_t j = j0 + threadIdx.x;
@@ -539,7 +542,7 @@ __global__ void __launch_bounds__(PT_SHADE_THREADS, PT_SHADE_MIN_WAVES) k_shade(
         v3 transmission = mk3(Ts.x, Ts.y, Ts.z);
         Rng rng;
         uint32_t pix, si;
-        div_wh.divmod(pid, si, pix);
+        SplitPathId(pid, spp, si, pix);
         div_w.divmod(pix, rng.y, rng.x);
         rng.z = first_sample + si; rng.w = __float_as_uint(Ts.w);
         const float specularStrength = 0.9f;
@@ -720,7 +723,7 @@ __global__ void __launch_bounds__(256) k_ao_rays(PtRtConsts c, DeviceScene sc, c
     const v3 hitPos = mk3(ro.x, ro.y, ro.z) + mk3(rd.x, rd.y, rd.z) * hr.x;
     Rng rng;
     uint32_t pix, si;
-    FastDiv(wh, 0x7fffffffu).divmod(pid, si, pix);
+    si = 0u; pix = pid;   // the AO pipeline renders one sample per batch: path id = pixel
     FastDiv(w, wh).divmod(pix, rng.y, rng.x);
     rng.z = first_sample + si; rng.w = 2u + 2u * i;
     v2 rand11;
@@ -774,14 +777,40 @@ __global__ void __launch_bounds__(256) k_resolve(const float4* __restrict__ st_L
     stats[ST_SKY] += counters[CTR_AT(CTR_MISS)];
     stats[ST_SAMPLES] += (unsigned long long)wh * samples;
   }
-  if (i >= wh) return;
-  float4 a = accum[i];
-  for (uint32_t s = 0; s < samples; ++s) {
-    float4 L = st_L[(size_t)s * wh + i];
-    if (isnan(L.x) || isnan(L.y) || isnan(L.z) || isinf(L.x) || isinf(L.y) || isinf(L.z)) { L.x = 0.0f; L.y = 0.0f; L.z = 0.0f; }
-    a.x += L.x; a.y += L.y; a.z += L.z;
+  // Path ids are pixel-major: a pixel's samples are contiguous (samples x 16 bytes), a thread's own pixel is not what its
+  // neighbours read. With samples a multiple of 8 the block streams 8 samples (one 128-byte line) of each of its 256
+  // pixels through LDS per round: 8 consecutive threads read one line, the transposed copy gives every thread its own
+  // pixel's 8 values, added in sample order as before. Other sample counts (small batches) take the plain loop.
+  __shared__ float4 s_t[256 * 9];   // [pixel][8 samples + 1 pad]: a thread's 8 reads fall into different banks from its neighbours'
+  const bool in_range = i < wh;
+  float4 a = in_range ? accum[i] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  if ((samples & 7u) == 0u) {   // block-uniform
+    const uint32_t pix0 = blockIdx.x * blockDim.x;
+    for (uint32_t s0 = 0; s0 < samples; s0 += 8u) {
+#pragma unroll
+      for (uint32_t it = 0; it < 8u; ++it) {
+        const uint32_t lp = it * 32u + (threadIdx.x >> 3), j = threadIdx.x & 7u;   // local pixel, sample within the round
+        if (pix0 + lp < wh) s_t[lp * 9u + j] = ld_stream(st_L + (size_t)(pix0 + lp) * samples + s0 + j);
+      }
+      __syncthreads();
+      if (in_range) {
+#pragma unroll
+        for (uint32_t j = 0; j < 8u; ++j) {
+          float4 L = s_t[threadIdx.x * 9u + j];
+          if (isnan(L.x) || isnan(L.y) || isnan(L.z) || isinf(L.x) || isinf(L.y) || isinf(L.z)) { L.x = 0.0f; L.y = 0.0f; L.z = 0.0f; }
+          a.x += L.x; a.y += L.y; a.z += L.z;
+        }
+      }
+      __syncthreads();
+    }
+  } else if (in_range) {
+    for (uint32_t s = 0; s < samples; ++s) {
+      float4 L = st_L[(size_t)i * samples + s];   // path ids are pixel-major
+      if (isnan(L.x) || isnan(L.y) || isnan(L.z) || isinf(L.x) || isinf(L.y) || isinf(L.z)) { L.x = 0.0f; L.y = 0.0f; L.z = 0.0f; }
+      a.x += L.x; a.y += L.y; a.z += L.z;
+    }
   }
-  accum[i] = a;
+  if (in_range) accum[i] = a;
 }
 
 __global__ void k_set_count(uint32_t* counter, uint32_t value) { *counter = value; }
@@ -984,7 +1013,7 @@ void launch_shade(const PtRtConsts& c, const DeviceScene& sc, const WavefrontBuf
 #define PT_LAUNCH_SHADE(E, F)                                                                                               \
   hipLaunchKernelGGL((k_shade<E, F>), dim3((unsigned)g), dim3(PT_SHADE_THREADS), 0, s, c, sc, wb.ray_o[in], wb.ray_d[in],   \
                      bounce == 0 ? (const uint32_t*)nullptr : wb.qid[in], wb.hits, wb.st_T, wb.st_L, wb.ray_o[out], wb.ray_d[out], \
-                     wb.qid[out], wb.sky_o, wb.sky_d, wb.counters, bounce, w, h, first_sample, russian_roulette ? 1u : 0u)
+                     wb.qid[out], wb.sky_o, wb.sky_d, wb.counters, bounce, w, h, first_sample, russian_roulette ? 1u : 0u, (uint32_t)(max_paths / ((uint64_t)w * h)))
   if (fused_primary && bounce == 0) {
     if (sc.instance_ext) PT_LAUNCH_SHADE(true, true); else PT_LAUNCH_SHADE(false, true);
   } else {

@@ -195,7 +195,7 @@ int ensure_wavefront_for(pt_ctx* ctx, WavefrontBuffers& wb, std::vector<void*>& 
   if ((rc = dev_alloc(ctx, &wb.st_L, paths, &allocs))) return rc;
   if ((rc = dev_alloc(ctx, &wb.sky_o, paths, &allocs))) return rc;
   if ((rc = dev_alloc(ctx, &wb.sky_d, paths, &allocs))) return rc;
-  if ((rc = dev_alloc(ctx, &wb.gen, (size_t)4, &allocs))) return rc;
+  if ((rc = dev_alloc(ctx, &wb.gen, (size_t)8, &allocs))) return rc;
   if ((rc = dev_alloc(ctx, &wb.counters, (size_t)CTR_WORDS, &allocs))) return rc;
   if (!wb.stats) {
     if ((rc = dev_alloc(ctx, &wb.stats, (size_t)ST_WORDS, &allocs))) return rc;

@@ -48,7 +48,20 @@ __device__ __forceinline__ void GetPrimaryRay(v2 pixel, uint32_t resX, uint32_t 
 // RayGen's ray set-up for path sample p of a batch (PathTracing.hlsl:40-61 with the Q1 deviation: position = uPixel +
 // jitter). One function for k_generate, the fused fetch of k_extend and bounce 0 of k_shade, so all three produce the
 // same bits. p = sample_in_batch * w*h + y*w + x; returns the RNG draw counter after the two jitter draws.
-struct PrimaryFrame { v3 corner, xAxis, yAxis, camPos; uint32_t w, h, wh, first_sample; };
+// Path ids of a batch of k samples per pixel are PIXEL-MAJOR: p = (y*w + x) * k + sample. The k samples of a pixel are
+// neighbours in every queue, so a wave of the coherent-primaries kernel holds one pixel's samples (k >= 64) or a few
+// adjacent pixels', secondary rays of a wave start from almost the same point, and the path-state accesses of consecutive
+// queue slots stay contiguous. (k = 1, the AO pipeline and pt_primary_hits: p = pixel.)
+struct PrimaryFrame { v3 corner, xAxis, yAxis, camPos; uint32_t w, h, wh, first_sample, k; };
+__device__ __forceinline__ void SplitPathId(uint32_t p, uint32_t k, uint32_t& si, uint32_t& pix) {
+  if ((k & (k - 1u)) == 0u) {   // wave-uniform: powers of two by shift
+    si = p & (k - 1u);
+    pix = p >> (31 - __clz((int)k));
+  } else {
+    pix = p / k;
+    si = p - pix * k;
+  }
+}
 __device__ __forceinline__ uint32_t PrimaryRayOfPixel(uint32_t px, uint32_t py, uint32_t si, const PrimaryFrame& f, v3& origin, v3& dir) {
   Rng rng = InitRNG(px, py, f.first_sample + si);
   v2 pixel;
@@ -65,21 +78,22 @@ __device__ __forceinline__ uint32_t PrimaryRayOfPixel(uint32_t px, uint32_t py, 
 }
 __device__ __forceinline__ uint32_t PrimaryRayOfPath(uint32_t p, const PrimaryFrame& f, v3& origin, v3& dir) {
   uint32_t pix, si, px, py;
-  FastDiv(f.wh, 0x7fffffffu).divmod(p, si, pix);     // path ids stay below 2^31 (pt_api.cpp batch sizing)
+  SplitPathId(p, f.k, si, pix);
   FastDiv(f.w, f.wh).divmod(pix, py, px);
   return PrimaryRayOfPixel(px, py, si, f, origin, dir);
 }
-// Fused primaries only (no k_generate pass, so nothing else sees the order): slot j of the bounce-0 queue is not path j
-// but the path of an 8x8-pixel tile order within its sample, so the 64 consecutive slots a wave fetches are a square
-// footprint instead of a 64x1 strip (fewer distinct BVH nodes per box test). The path id -- what the RNG, the path state
-// and k_resolve are keyed on -- keeps its meaning p = sample * w*h + y*w + x, so the target bits do not change. Frames
-// whose width or height is not a multiple of 8 keep the identity order (wave-uniform test). Returns the path id.
+// Fused primaries only (no k_generate pass, so nothing else sees the order): slot j of the bounce-0 queue enumerates the
+// PIXELS in 8x8-pixel tile order (sample-minor as the path ids), so the 64 consecutive slots a wave fetches are the samples
+// of one pixel or of a few pixels of one tile: a footprint of a pixel or two instead of a 64x1 strip (fewer distinct BVH
+// nodes per box test; what k_extend_packet lives on). The path id -- what the RNG, the path state and k_resolve are keyed
+// on -- keeps its meaning, so the target bits do not change. Frames whose width or height is not a multiple of 8 keep the
+// row order of pixels (wave-uniform test). Returns the path id.
 #ifndef PT_PRIMARY_TILES
 #define PT_PRIMARY_TILES 1
 #endif
 __device__ __forceinline__ uint32_t PrimaryRayOfSlot(uint32_t j, const PrimaryFrame& f, v3& origin, v3& dir) {
   uint32_t r, si, px, py;
-  FastDiv(f.wh, 0x7fffffffu).divmod(j, si, r);
+  SplitPathId(j, f.k, si, r);
   if (PT_PRIMARY_TILES && ((f.w | f.h) & 7u) == 0u) {
     uint32_t ty, tx;
     FastDiv(f.w >> 3, f.wh >> 6).divmod(r >> 6, ty, tx);
@@ -89,7 +103,7 @@ __device__ __forceinline__ uint32_t PrimaryRayOfSlot(uint32_t j, const PrimaryFr
     FastDiv(f.w, f.wh).divmod(r, py, px);
   }
   (void)PrimaryRayOfPixel(px, py, si, f, origin, dir);
-  return si * f.wh + py * f.w + px;
+  return (py * f.w + px) * f.k + si;
 }
 // GetLuminance — Common.hlsl:191-194
 __device__ __forceinline__ float GetLuminance(v3 c) { return dot(c, mk3(0.2126f, 0.7152f, 0.0722f)); }
