@@ -10,7 +10,7 @@ timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpur
 echo "trace ok"
 bash tools/prof_pmc.sh ${TAG}_atrium --primary-packet 1 || exit 1
 python3 tools/summarize_pmc.py ${TAG}_atrium > gpurun_out/pmc_${TAG}_atrium_summary.txt
-bash tools/prof_pmc.sh ${TAG}_street --workload street --primary-packet 0 || exit 1
+bash tools/prof_pmc.sh ${TAG}_street --workload street --primary-packet 1 || exit 1
 python3 tools/summarize_pmc.py ${TAG}_street > gpurun_out/pmc_${TAG}_street_summary.txt
 bash tools/prof_pmc.sh ${TAG}_courtyard --workload courtyard --width 3840 --height 2160 --spp-per-step 16 --primary-packet 1 || exit 1
 python3 tools/summarize_pmc.py ${TAG}_courtyard > gpurun_out/pmc_${TAG}_courtyard_summary.txt
