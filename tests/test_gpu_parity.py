@@ -874,9 +874,21 @@ def test_batch_size_never_changes_the_image(ctx, oracle):
             ctx.accum_reset(w, h)
             ctx.render(c, w, h, 1, 5)
             imgs.append(ctx.accum_read_sum()[0])
+        assert all(np.array_equal(imgs[0], im) for im in imgs[1:])
+        # k_resolve's two paths: batches of a multiple of 8 samples go through the LDS transpose (path ids are pixel-major),
+        # others through the per-thread loop; frames that do not fill the last 256-pixel block, one and several rounds
+        for (w2, h2), n in (((37, 23), 24), ((64, 8), 16), ((9, 5), 8)):
+            c2 = lookat_consts(w2, h2, scenes.ATRIUM_CAM, depth=2)
+            ref = None
+            for spb in (1, 8, 0, 3):
+                ctx.set_option(api.PT_OPT_SAMPLES_PER_BATCH, spb)
+                ctx.accum_reset(w2, h2)
+                ctx.render(c2, w2, h2, 2, n)
+                img = ctx.accum_read_sum()[0]
+                ref = img if ref is None else ref
+                assert np.array_equal(ref.view(np.uint32), img.view(np.uint32)), (w2, h2, spb)
     finally:
         ctx.set_option(api.PT_OPT_SAMPLES_PER_BATCH, 0)
-    assert all(np.array_equal(imgs[0], im) for im in imgs[1:])
 
 
 def test_pt_reduce_adds_targets_of_several_contexts(ctx, cornell):
