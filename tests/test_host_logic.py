@@ -43,6 +43,24 @@ def test_rtconsts_layout_matches_reference_offsets():
     assert C.sizeof(api.PtMaterial) == 16 and C.sizeof(api.PtInstanceDesc) == 72
 
 
+def test_ctypes_mirrors_have_the_c_header_struct_sizes(tmp_path):
+    """The Python mirror (pathtracer_amd/api.py) and include/pt_api.h must agree on every struct that crosses the C ABI by
+    pointer: a C program compiled against the header prints sizeof / offsetof, ctypes must report the same."""
+    import subprocess
+    src = tmp_path / "sizes.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "pt_api.h"\nint main(void) {\n'
+                   '  printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(PtStats), offsetof(PtStats, extend_launches_bounce), '
+                   'offsetof(PtStats, packet_launches), offsetof(PtStats, packet_cal_ms), sizeof(PtSceneInfo), sizeof(PtAtmosphere), sizeof(PtInstanceDesc), '
+                   'sizeof(PtRtConsts), sizeof(PtMaterialExt), sizeof(PtMeshDesc));\n  return 0;\n}\n')
+    exe = tmp_path / "sizes"
+    subprocess.check_call(["gcc", "-std=c11", "-I", os.path.join(ROOT, "include"), "-o", str(exe), str(src)])
+    got = [int(x) for x in subprocess.check_output([str(exe)]).split()]
+    want = [C.sizeof(api.PtStats), api.PtStats.extend_launches_bounce.offset, api.PtStats.packet_launches.offset, api.PtStats.packet_cal_ms.offset,
+            C.sizeof(api.PtSceneInfo), C.sizeof(api.PtAtmosphere), C.sizeof(api.PtInstanceDesc), C.sizeof(api.PtRtConsts), C.sizeof(api.PtMaterialExt),
+            C.sizeof(api.PtMeshDesc)]
+    assert got == want
+
+
 def test_no_device_error_is_reported_not_hidden():
     """Without a GPU the product must fail loudly (there is no CPU fallback)."""
     import torch
