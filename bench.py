@@ -290,6 +290,7 @@ def main():
         # the algorithmic fp32 rate against the vector peak (never above 1).
         if valu and (not fabric or valu["frac"] >= fabric["frac_of_hbm_peak"]):
             top = {"bound": "valu", "achieved": valu["achieved_ginstr_per_s"], "peak": VALU_PEAK_GINSTR, "unit": "Ginstr/s", "frac": valu["frac"],
+                   "frac_of_mix_roof": valu["frac_of_mix_roof"], "mix_roof": valu["mix_roof_ginstr_per_s"],
                    "basis": "SQ_INSTS_VALU per launch (profiles/%s/pmc_traffic.json) / live HIP-event launch time; peak = 256 CUs x 4 SIMD x 2.4 GHz / 2 cycles" % PMC_ROUND}
         elif fabric:
             top = {"bound": "hbm", "achieved": fabric["achieved_gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": fabric["frac_of_hbm_peak"],
