@@ -107,6 +107,9 @@ __device__ __forceinline__ void block_append2(BlockAppendLds& L, int parity, uin
       run += c;
     }
     L.base[parity][q] = run ? atomicAdd(q == 0u ? counter0 : counter1, run) : 0u;
+#ifdef PT_EXP_SHADE_EXTRA_ATOMIC   // experiment: a second, dependent returning atomic per append: is k_shade bound by that round trip?
+    L.base[parity][q] += atomicAdd(counter0 + 64 * 40 + q * 64, L.base[parity][q] & 1u) & 0u;
+#endif
   }
   __syncthreads();
   const unsigned long long below = (1ull << lane) - 1ull;
