@@ -163,6 +163,29 @@ void Camera::GetVerticesOnNearPlane(float3 v[4]) const {
   v[3] = add(sub(c, mul(right, halfW)), mul(up, halfH));
 }
 
+void Camera::GetViewProj(float m[4][4]) const {
+  double view[4][4] = {{0}}, proj[4][4] = {{0}};
+  const double pos[3] = {myPosition.x, myPosition.y, myPosition.z};
+  for (int r = 0; r < 3; ++r) {
+    double t = 0.0;
+    for (int c = 0; c < 3; ++c) { view[r][c] = myOrientation[r][c]; t += (double)myOrientation[r][c] * pos[c]; }
+    view[r][3] = -t;
+  }
+  view[3][3] = 1.0;
+  const double f = 1.0 / std::tan(myFovDeg * 3.14159265358979323846 / 180.0 * 0.5), n = myNear, fr = myFar;
+  proj[0][0] = f / ((double)myWidth / myHeight);
+  proj[1][1] = f;
+  proj[2][2] = fr / (fr - n);
+  proj[2][3] = -n * fr / (fr - n);
+  proj[3][2] = 1.0;
+  for (int r = 0; r < 4; ++r)
+    for (int c = 0; c < 4; ++c) {
+      double a = 0.0;
+      for (int k = 0; k < 4; ++k) a += proj[r][k] * view[k][c];
+      m[r][c] = (float)a;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ Sky
 void SetupEarthAtmosphere(PtAtmosphere& p) {
   const float EarthBottomRadius = 6360000.0f, EarthTopRadius = 6460000.0f;
@@ -206,6 +229,8 @@ PathTracer::PathTracer(int aDevice, uint32_t w, uint32_t h) : myWindowWidth(w), 
   myCamera.myHeight = (float)h;
   UpdateOutputTexture();
   InitSky();
+  myCamera.GetViewProj(myLastViewMat);
+  myLastSky = SnapshotSky();
 }
 
 PathTracer::~PathTracer() {
@@ -285,8 +310,31 @@ void PathTracer::OnWindowResized(uint32_t w, uint32_t h) {
   RestartAccumulation();
 }
 
+bool PathTracer::CameraHasChanged() const {
+  float m[4][4];
+  myCamera.GetViewProj(m);
+  for (int i = 0; i < 4; ++i)
+    for (int k = 0; k < 4; ++k)
+      if (std::fabs(m[i][k] - myLastViewMat[i][k]) > 0.0001f) return true;
+  return false;
+}
+
+PathTracer::SkySnapshot PathTracer::SnapshotSky() const { return SkySnapshot{mySky->mySunDir, mySky->mySunIlluminance, mySky->myAtmosphereParams}; }
+
+void PathTracer::SkySettingsChanged() {
+  mySkyDirty = true;
+  RestartAccumulation();
+}
+
 void PathTracer::Update() {
   if (!myAccumulate) RestartAccumulation();   // always render frame 0 only (PathTracer.cpp:562-564)
+  const SkySnapshot now = SnapshotSky();
+  if (memcmp(&now, &myLastSky, sizeof(now)) != 0) {   // mySky_Imgui.HaveSettingsChanged() (:566)
+    myLastSky = now;
+    SkySettingsChanged();
+  }
+  if (CameraHasChanged()) RestartAccumulation();      // (:566-568)
+  myCamera.GetViewProj(myLastViewMat);                // (:570)
 }
 
 PtRtConsts PathTracer::BuildRtConsts() const {

@@ -49,6 +49,9 @@ public:
   bool myIsOrtho = false;
   void LookAt(float3 anEye, float3 aTarget, float3 anUp = {0, 1, 0});
   void GetVerticesOnNearPlane(float3 someVerticesOut[4]) const;   // v0 BL, v1 BR, v2 TR, v3 TL
+  // myViewProj as CameraHasChanged reads it (PathTracer.cpp:446-453): proj * view, row-major [row][col]; adopted definition
+  // (FANCY's UpdateView / UpdateProjection are absent): camera axes as the view rotation, left-handed D3D perspective
+  void GetViewProj(float aMatOut[4][4]) const;
 };
 
 class PtException : public std::runtime_error {
@@ -82,7 +85,9 @@ public:
   void InitSky();                                                      // :151-154
   void InitRtScene(const SceneData& aScene);                           // :171-339
   void OnWindowResized(uint32_t aWidth, uint32_t aHeight);             // :439-444
-  void Update();                                                       // :557-571 (restart when !myAccumulate)
+  void Update();                                                       // :557-571: restart when !myAccumulate, camera moved, sky changed
+  bool CameraHasChanged() const;                                       // :446-453 (epsilon 1e-4 on the view-projection matrix)
+  void SkySettingsChanged();                                           // Sky_Imgui::HaveSettingsChanged -> RestartAccumulation (:566-568)
   void Render(uint32_t aNumFrames = 1) { RenderRT(aNumFrames); }       // :573-595, RT branch
   void RenderRT(uint32_t aNumFrames = 1);                              // :659-787
   void UpdateOutputTexture();                                          // :834-878
@@ -109,9 +114,13 @@ public:
   float myLightStrength = 100.0f;
   float myPhongSpecularPower = 10.0f;
   bool mySkyDirty = true;
+  float myLastViewMat[4][4];                                           // PathTracer.h:115
 
 private:
   void Check(int aCode) const;
+  struct SkySnapshot { float3 mySunDir, mySunIlluminance; PtAtmosphere myAtmosphere; };
+  SkySnapshot myLastSky;
+  SkySnapshot SnapshotSky() const;
 };
 
 }  // namespace pth

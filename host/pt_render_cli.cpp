@@ -65,6 +65,7 @@ int main(int argc, char** argv) {
     auto t1 = std::chrono::steady_clock::now();
     if (!app.WritePfm(argv[2], tonemap)) { fprintf(stderr, "cannot write %s\n", argv[2]); return 1; }
     PtStats st;
+    st.struct_size = (uint32_t)sizeof(st);   // versioned by size (include/pt_api.h)
     pt_stats_get(app.myCtx, &st);
     const double s = std::chrono::duration<double>(t1 - t0).count();
     printf("%ux%u, %u frames, %llu rays in %.3f s (%.1f Mrays/s) -> %s\n", app.myOutputWidth, app.myOutputHeight, spp,

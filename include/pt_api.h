@@ -159,7 +159,12 @@ typedef struct PtRay {
   float tmax;
 } PtRay;
 
+/* Versioned by size: the caller sets struct_size = sizeof(PtStats) of the header IT was built against before calling
+ * pt_stats_get; the library fills at most that many bytes (and writes back how many it filled). Members are only ever
+ * APPENDED from this layout on, so a host built against an older header keeps reading the fields it knows. */
 typedef struct PtStats {
+  uint32_t struct_size;    /* in: sizeof(PtStats) of the caller's header; out: bytes filled (<= in) */
+  uint32_t reserved0;
   uint64_t samples;        /* pixel-samples completed since the last pt_stats_reset */
   uint64_t rays;           /* TraceRay-equivalents issued (primary included) */
   uint64_t shaded_hits;    /* ClosestHit-equivalents */
@@ -191,7 +196,7 @@ typedef struct PtSceneInfo {
   double build_ms;
 } PtSceneInfo;
 
-/* options for pt_set_option */
+/* options for pt_set_option (the traversal kernel's tuning knobs are not here: include/pt_api_tuning.h) */
 enum {
   PT_OPT_COUNT_TRAVERSAL = 1, /* 0/1: run the counting instantiation of the extend kernel (fills nodes_visited/tris_tested) */
   PT_OPT_TIME_KERNELS = 2,    /* 0/1: bracket kernels with HIP events (fills extend_ms/render_ms) */
@@ -199,27 +204,21 @@ enum {
   PT_OPT_SKY_MODE = 4,        /* 0 = ray-march on every miss (reference, SampleSky.hlsl:7-47); 1 = 256x256 direction LUT built per pt_render
                                  for the camera position (extension after sky/compute_skyView_lut.hlsl; image relMSE vs mode 0 < 1e-4;
                                  cameras above 50 km of altitude are marched as in mode 0) */
-  PT_OPT_EXTEND_FETCH_MIN = 5,     /* tuning: refill idle lanes of a wave once this many (1..64) are idle */
-  PT_OPT_EXTEND_POSTPONE_PCT = 6,  /* tuning: postpone triangle tests while < this % of busy lanes have any (0 = never) */
-  PT_OPT_EXTEND_BLOCKS_PER_CU = 7, /* tuning: persistent grid = CUs x this (0 = occupancy query) */
-  PT_OPT_EXTEND_LDS_STACK = 8,     /* tuning: per-lane traversal-stack entries kept in LDS (rest spills to HBM) */
-  PT_OPT_EXTEND_DEFER = 9,         /* tuning: 0 = postpone triangles on the stack; N>0 = park up to N groups per lane */
   PT_OPT_RUSSIAN_ROULETTE = 10,    /* 0/1 (default 0 = reference behaviour): unbiased Russian roulette after bounce 3 — survive with
                                       q = clamp(luminance(throughput), 0.05, 1), throughput /= q (extension; the reference only has
                                       a commented-out, biased sketch at PathTracing.hlsl:110-124) */
-  PT_OPT_EXTEND_TOP_NODES = 12,    /* tuning: BVH nodes (breadth-first order, i.e. the top of the tree) that every traversal block keeps in LDS */
-  PT_OPT_EXTEND_CONTINUE_PCT = 13, /* tuning: a triangle phase of the deferred schedule continues while >= this % of busy lanes have work */
+  PT_OPT_PIPELINE = 11,            /* 0/1 (default 0): split every batch of >= 2 samples into two halves that run on two streams (the
+                                      second one internal): one half's shade kernels and kernel drains run under the other half's
+                                      extend, +1..2 % throughput, results bit-identical; off by default because concurrent kernels
+                                      blur the per-kernel durations that profiles and the bench's roofline are built on */
   PT_OPT_FUSED_PRIMARY = 14,       /* 0/1 (default 1): pt_render computes primary rays inside the traversal and shading kernels
                                       (RayGen's ray set-up, PathTracing.hlsl:40-61) instead of writing them to the bounce-0 queue
                                       and reading them back: 160 B of memory traffic per path less, results bit-identical */
-  PT_OPT_PRIMARY_PACKET = 15,      /* which kernel traces the fused primaries of pt_render (coherent 8x8-pixel tiles): 0 = the general per-lane
+  PT_OPT_PRIMARY_PACKET = 15       /* which kernel traces the fused primaries of pt_render (coherent 8x8-pixel tiles): 0 = the general per-lane
                                       traversal, 1 = one BVH walk per wave with wave-uniform node fetches (k_extend_packet), 2 (default) = the
-                                      faster of the two, timed once per scene and frame size on <= 2^24 primaries (one stream
-                                      synchronisation inside that pt_render call). Same hit records either way. */
-  PT_OPT_PIPELINE = 11             /* 0/1 (default 0): split every batch of >= 2 samples into two halves that run on two streams (the
-                                      second one internal): one half's shade kernels and kernel drains run under the other half's
-                                      extend, +2..5 % throughput, results bit-identical; off by default because concurrent kernels
-                                      blur the per-kernel durations that profiles and the bench's roofline are built on */
+                                      faster of the two, timed once per scene and frame size on <= 2^24 primaries. That FIRST pt_render call
+                                      per scene and frame size blocks the host (one stream synchronisation) and cannot be stream-captured;
+                                      callers that need every call asynchronous set 0 or 1. Same hit records either way. */
 };
 
 /* ---- lifetime (replaces the RenderCore device + handle ownership, PathTracer.cpp:45-77,417-437) ---- */
@@ -332,7 +331,7 @@ int pt_debug_read_queue(pt_ctx* ctx, uint32_t bounce, PtRay* host_rays, uint64_t
    (capacities are in records). Lets tests walk the very hierarchy the kernel walks (tests/walker/). */
 int pt_debug_read_bvh(pt_ctx* ctx, void* nodes, uint64_t node_capacity, void* tris, uint64_t tri_capacity,
                       uint64_t* num_nodes, uint64_t* num_tris, float* scene_mag, uint32_t* record_bytes);
-int pt_stats_get(pt_ctx* ctx, PtStats* out);   /* synchronises the stream first */
+int pt_stats_get(pt_ctx* ctx, PtStats* out);   /* out->struct_size must be set (see PtStats); synchronises the stream first */
 int pt_stats_reset(pt_ctx* ctx);
 
 /* function ids for pt_debug_eval: floats per input row -> floats per output row */

@@ -34,17 +34,19 @@ PT_OPT_COUNT_TRAVERSAL = 1
 PT_OPT_TIME_KERNELS = 2
 PT_OPT_SAMPLES_PER_BATCH = 3
 PT_OPT_SKY_MODE = 4
-PT_OPT_EXTEND_FETCH_MIN = 5
-PT_OPT_EXTEND_POSTPONE_PCT = 6
-PT_OPT_EXTEND_BLOCKS_PER_CU = 7
-PT_OPT_EXTEND_LDS_STACK = 8
-PT_OPT_EXTEND_DEFER = 9
 PT_OPT_RUSSIAN_ROULETTE = 10
 PT_OPT_PIPELINE = 11
-PT_OPT_EXTEND_TOP_NODES = 12
-PT_OPT_EXTEND_CONTINUE_PCT = 13
 PT_OPT_FUSED_PRIMARY = 14
 PT_OPT_PRIMARY_PACKET = 15
+
+# include/pt_api_tuning.h: schedule knobs of the traversal kernel, set through pt_debug_set_tuning (tools and tests only)
+PT_TUNE_EXTEND_FETCH_MIN = 5
+PT_TUNE_EXTEND_POSTPONE_PCT = 6
+PT_TUNE_EXTEND_BLOCKS_PER_CU = 7
+PT_TUNE_EXTEND_LDS_STACK = 8
+PT_TUNE_EXTEND_DEFER = 9
+PT_TUNE_EXTEND_TOP_NODES = 12
+PT_TUNE_EXTEND_CONTINUE_PCT = 13
 
 (PT_FN_RAND01, PT_FN_FRESNEL, PT_FN_SPEC_PROB, PT_FN_SAMPLE_PHONG, PT_FN_EVAL_PHONG, PT_FN_COS_HEMISPHERE,
  PT_FN_LAMBERT, PT_FN_SKY, PT_FN_PRIMARY_RAY, PT_FN_SKY_VIEW_LUT, PT_FN_GGX_SAMPLE, PT_FN_ALBEDO_PATTERN) = range(12)
@@ -118,8 +120,8 @@ class PtMaterialExt(C.Structure):   # extension for BASELINE C4/C5, not in the r
                 ("pattern_scale", C.c_float), ("flags", C.c_uint32), ("reserved", C.c_uint32 * 3)]
 
 
-class PtStats(C.Structure):
-    _fields_ = [("samples", C.c_uint64), ("rays", C.c_uint64), ("shaded_hits", C.c_uint64), ("sky_misses", C.c_uint64),
+class PtStats(C.Structure):   # versioned by size: struct_size is set by the caller (context.Context.stats does), members are append-only
+    _fields_ = [("struct_size", C.c_uint32), ("reserved0", C.c_uint32), ("samples", C.c_uint64), ("rays", C.c_uint64), ("shaded_hits", C.c_uint64), ("sky_misses", C.c_uint64),
                 ("nodes_visited", C.c_uint64), ("tris_tested", C.c_uint64), ("extend_launches", C.c_uint64),
                 ("extend_ms", C.c_double), ("render_ms", C.c_double),
                 ("rays_bounce", C.c_uint64 * 16), ("extend_ms_bounce", C.c_double * 16),
@@ -140,7 +142,7 @@ HIT_DTYPE = np.dtype([("t", np.float32), ("u", np.float32), ("v", np.float32), (
 RAY_DTYPE = np.dtype([("origin", np.float32, 3), ("tmin", np.float32), ("dir", np.float32, 3), ("tmax", np.float32)])
 assert VERTEX_DTYPE.itemsize == 32 and HIT_DTYPE.itemsize == 16 and RAY_DTYPE.itemsize == 32
 
-# every symbol include/pt_api.h declares: name -> (restype, argtypes)
+# every symbol include/pt_api.h and include/pt_api_tuning.h declare: name -> (restype, argtypes)
 _P = C.c_void_p
 SYMBOLS = {
     "pt_create": (C.c_int, [C.c_int, C.POINTER(_P)]),
@@ -149,6 +151,7 @@ SYMBOLS = {
     "pt_set_stream": (C.c_int, [_P, _P]),
     "pt_synchronize": (C.c_int, [_P]),
     "pt_set_option": (C.c_int, [_P, C.c_int, C.c_int64]),
+    "pt_debug_set_tuning": (C.c_int, [_P, C.c_int, C.c_int64]),   # include/pt_api_tuning.h
     "pt_scene_create": (C.c_int, [_P, C.POINTER(PtMeshDesc), C.c_uint32, C.POINTER(PtInstanceDesc), C.c_uint32,
                                   C.POINTER(PtMaterial), C.c_uint32, C.c_uint32]),
     "pt_scene_set_material_ext": (C.c_int, [_P, C.POINTER(PtMaterialExt), C.c_uint32]),

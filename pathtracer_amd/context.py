@@ -215,6 +215,10 @@ class Context:
     def set_option(self, opt, value):
         self._ck(self.lib.pt_set_option(self.h, opt, int(value)))
 
+    def set_tuning(self, knob, value):
+        """include/pt_api_tuning.h: schedule knobs of the traversal kernel (api.PT_TUNE_*); hit records never depend on them."""
+        self._ck(self.lib.pt_debug_set_tuning(self.h, knob, int(value)))
+
     def set_stream(self, stream_handle):
         self._ck(self.lib.pt_set_stream(self.h, C.c_void_p(stream_handle)))
 
@@ -223,6 +227,7 @@ class Context:
 
     def stats(self):
         s = api.PtStats()
+        s.struct_size = C.sizeof(api.PtStats)
         self._ck(self.lib.pt_stats_get(self.h, C.byref(s)))
         return s
 

@@ -4,6 +4,7 @@
 #include "bvh_builder.h"
 
 #include <algorithm>
+#include <array>
 #include <atomic>
 #include <cfloat>
 #include <chrono>
@@ -23,9 +24,15 @@ struct Node2 {
   uint32_t first, count;  // range in the permuted primitive index array
 };
 
-struct Prim {
-  float lo[3], hi[3], c[3];
+// A reference: (part of) a primitive with the box of that part. Without spatial splits every primitive has exactly one;
+// a spatial split cuts a reference in two, each half keeping the box of its side of the plane.
+struct Ref {
+  float lo[3], hi[3];
+  uint32_t prim;
 };
+
+// the one or two triangles of a primitive record (b = 0xFFFFFFFF: a single triangle)
+struct PrimRef { uint32_t a, b; };
 
 // Areas and SAH costs are doubles: a single far-away (but finite) vertex makes fp32 areas overflow to +inf, and an
 // infinite cost poisons every comparison of the builder and of the collapse.
@@ -34,32 +41,89 @@ static inline double half_area(const float* lo, const float* hi) {
   return dx * dy + dy * dz + dz * dx;
 }
 
+struct Box3 {
+  float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+  void grow(const float* l, const float* h) {
+    for (int k = 0; k < 3; ++k) { lo[k] = std::min(lo[k], l[k]); hi[k] = std::max(hi[k], h[k]); }
+  }
+  void grow(const Box3& b) { grow(b.lo, b.hi); }
+  bool valid() const { return lo[0] <= hi[0] && lo[1] <= hi[1] && lo[2] <= hi[2]; }
+  double area() const { return valid() ? half_area(lo, hi) : 0.0; }
+};
+
 #ifndef PT_BVH_BINS
 #define PT_BVH_BINS 16
 #endif
 constexpr int kBins = PT_BVH_BINS;
-constexpr uint32_t kParallelThreshold = 1u << 15;
+constexpr uint32_t kParallelThreshold = 1u << 15;   // subtrees above this size become tasks of their own
+constexpr size_t kParallelPass = 1u << 19;          // passes over more references than this are split over the threads
+constexpr int kMaxDepth2 = 160;                     // binary levels after which spatial splits stop (the 8-wide tree is <= 62 deep)
 
-class Builder2 {
+// Bounds of (triangle ∩ {lo <= x[axis] <= hi}) grown into (blo, bhi): the vertices inside the slab and the points where
+// the edges cross its two planes are exactly the vertices of the clipped polygon. Returns false when nothing is inside.
+static bool clip_triangle(const float* v, int axis, double lo, double hi, double* blo, double* bhi) {
+  bool any = false;
+  auto grow = [&](const double* p) {
+    for (int k = 0; k < 3; ++k) { blo[k] = std::min(blo[k], p[k]); bhi[k] = std::max(bhi[k], p[k]); }
+    any = true;
+  };
+  for (int i = 0; i < 3; ++i) {
+    const float* p = v + 3 * i;
+    const float* q = v + 3 * ((i + 1) % 3);
+    const double pa = p[axis], qa = q[axis];
+    if (pa >= lo && pa <= hi) { const double pp[3] = {p[0], p[1], p[2]}; grow(pp); }
+    for (int side = 0; side < 2; ++side) {
+      const double pl = side ? hi : lo;
+      if ((pa < pl && qa > pl) || (pa > pl && qa < pl)) {
+        const double t = (pl - pa) / (qa - pa);
+        double x[3];
+        for (int k = 0; k < 3; ++k) x[k] = (double)p[k] + t * ((double)q[k] - (double)p[k]);
+        x[axis] = pl;
+        grow(x);
+      }
+    }
+  }
+  return any;
+}
+
+static inline float round_down(double x) { float f = (float)x; return (double)f > x ? std::nextafterf(f, -FLT_MAX) : f; }
+static inline float round_up(double x) { float f = (float)x; return (double)f < x ? std::nextafterf(f, FLT_MAX) : f; }
+
+// Top-down builder over references: binned SAH object splits, and (Stich, Friedrich, Dietrich, "Spatial Splits in Bounding
+// Volume Hierarchies", HPG 2009) binned SPATIAL splits where the two sides of the best object split overlap: a long or
+// diagonal triangle is then referenced from several leaves, each with the tight box of its piece, instead of dragging one
+// loose box through the hierarchy. Leaves hold one reference. A triangle reached through several leaves is simply tested
+// more than once: the closest hit with its lower-id tie-break does not depend on that, so hit records cannot change.
+// Deterministic for any thread count: the extra-reference budget is handed down the tree in proportion to the box areas
+// of each side's references, never taken from a shared counter.
+class SplitBuilder {
  public:
-  Builder2(const std::vector<Prim>& prims, std::vector<uint32_t>& order, std::vector<Node2>& nodes, int threads)
-      : prims_(prims), order_(order), nodes_(nodes), threads_(threads) {}
+  SplitBuilder(const float* verts, const std::vector<PrimRef>& prims, float pad, std::vector<Node2>& nodes, int threads, double alpha, double gain)
+      : verts_(verts), prims_(prims), pad_(pad), nodes_(nodes), threads_(threads), alpha_(alpha), gain_(gain) {
+    if (const char* e = getenv("PT_BVH_SPLIT_SINGLE_AXIS")) single_axis_below_ = atoi(e);
+  }
 
-  void run() {
-    const uint32_t n = (uint32_t)order_.size();
-    nodes_.resize(n ? 2 * (size_t)n - 1 : 1);
+  // refs: one per primitive; extra: how many more references spatial splits may create in total
+  void run(std::vector<Ref>&& refs, uint64_t extra) {
+    const size_t n = refs.size();
+    nodes_.resize(n ? 2 * (n + extra) : 1);
     next_node_.store(1);
     outstanding_.store(1);
-    tasks_.push_back({0, 0, n});
+    Box3 b;
+    for (const Ref& r : refs) b.grow(r.lo, r.hi);
+    root_area_ = std::max(b.area(), 1e-300);
+    tasks_.push_back(Task{0, 0, extra, std::move(refs)});
     std::vector<std::thread> pool;
     for (int t = 1; t < threads_; ++t) pool.emplace_back([this] { worker(); });
     worker();
     for (auto& th : pool) th.join();
     nodes_.resize(next_node_.load());
   }
+  uint64_t spatial_splits() const { return n_spatial_.load(); }
 
  private:
-  struct Task { uint32_t node, begin, end; };
+  struct Task { uint32_t node; int depth; uint64_t budget; std::vector<Ref> refs; };
+  struct Bin { Box3 box; uint32_t n = 0, enter = 0, leave = 0; };
 
   void worker() {
     for (;;) {
@@ -68,10 +132,10 @@ class Builder2 {
         std::unique_lock<std::mutex> lk(mu_);
         cv_.wait(lk, [this] { return !tasks_.empty() || outstanding_.load() == 0; });
         if (tasks_.empty()) return;
-        tk = tasks_.back();
+        tk = std::move(tasks_.back());
         tasks_.pop_back();
       }
-      process(tk);
+      process(std::move(tk));
       if (outstanding_.fetch_sub(1) == 1) {
         std::lock_guard<std::mutex> lk(mu_);
         cv_.notify_all();
@@ -79,123 +143,321 @@ class Builder2 {
     }
   }
 
-  void spawn(const Task& t) {
+  void spawn(Task&& t) {
     outstanding_.fetch_add(1);
     {
       std::lock_guard<std::mutex> lk(mu_);
-      tasks_.push_back(t);
+      tasks_.push_back(std::move(t));
     }
     cv_.notify_one();
   }
 
-  // Splits [begin,end) of node; returns mid and allocates the two children. Returns false if it became a leaf.
-  bool split(const Task& tk, uint32_t& mid, uint32_t& left) {
-    Node2& nd = nodes_[tk.node];
-    float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
-    float clo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, chi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
-    for (uint32_t i = tk.begin; i < tk.end; ++i) {
-      const Prim& p = prims_[order_[i]];
-      for (int a = 0; a < 3; ++a) {
-        lo[a] = std::min(lo[a], p.lo[a]); hi[a] = std::max(hi[a], p.hi[a]);
-        clo[a] = std::min(clo[a], p.c[a]); chi[a] = std::max(chi[a], p.c[a]);
-      }
-    }
-    for (int a = 0; a < 3; ++a) { nd.lo[a] = lo[a]; nd.hi[a] = hi[a]; }
-    nd.first = tk.begin;
-    nd.count = tk.end - tk.begin;
-    nd.left = 0;
-    if (nd.count <= 1) return false;
+  // f(begin, end, slot) over [0, n) in `slots` contiguous chunks; the chunks of a large pass run on their own threads
+  // (only the top few nodes of a big scene are that large, and the pool is idle while they are processed)
+  template <class F>
+  int chunked(size_t n, F&& f) const {
+    const int slots = (threads_ > 1 && n >= kParallelPass) ? threads_ : 1;
+    if (slots == 1) { f((size_t)0, n, 0); return 1; }
+    std::vector<std::thread> th;
+    for (int s = 1; s < slots; ++s) th.emplace_back([&, s] { f(n * s / slots, n * (s + 1) / slots, s); });
+    f((size_t)0, n / slots, 0);
+    for (auto& t : th) t.join();
+    return slots;
+  }
 
-    struct Bin { float lo[3], hi[3]; uint32_t n; };
-    Bin bins[3][kBins];
-    for (int a = 0; a < 3; ++a)
-      for (int b = 0; b < kBins; ++b) {
-        bins[a][b].n = 0;
-        for (int k = 0; k < 3; ++k) { bins[a][b].lo[k] = FLT_MAX; bins[a][b].hi[k] = -FLT_MAX; }
-      }
-    float scale[3];
-    for (int a = 0; a < 3; ++a) { float ext = chi[a] - clo[a]; scale[a] = ext > 0.0f ? (float)kBins / ext : 0.0f; }
-    for (uint32_t i = tk.begin; i < tk.end; ++i) {
-      const Prim& p = prims_[order_[i]];
-      for (int a = 0; a < 3; ++a) {
-        if (scale[a] == 0.0f) continue;
-        int b = (int)((p.c[a] - clo[a]) * scale[a]);
-        b = b < 0 ? 0 : (b >= kBins ? kBins - 1 : b);
-        Bin& bn = bins[a][b];
-        bn.n++;
-        for (int k = 0; k < 3; ++k) { bn.lo[k] = std::min(bn.lo[k], p.lo[k]); bn.hi[k] = std::max(bn.hi[k], p.hi[k]); }
+  // the part of a reference's primitive inside lo <= x[axis] <= hi, as a box (within the reference's own box); false = none
+  bool clip_ref(const Ref& r, int axis, double lo, double hi, Box3& out) const {
+    double blo[3] = {DBL_MAX, DBL_MAX, DBL_MAX}, bhi[3] = {-DBL_MAX, -DBL_MAX, -DBL_MAX};
+    const PrimRef& pr = prims_[r.prim];
+    bool any = clip_triangle(verts_ + (size_t)pr.a * 9, axis, lo, hi, blo, bhi);
+    if (pr.b != 0xFFFFFFFFu) any = clip_triangle(verts_ + (size_t)pr.b * 9, axis, lo, hi, blo, bhi) || any;
+    if (!any) return false;
+    for (int k = 0; k < 3; ++k) {
+      out.lo[k] = std::max(r.lo[k], round_down(blo[k]) - pad_);
+      out.hi[k] = std::min(r.hi[k], round_up(bhi[k]) + pad_);
+    }
+    return out.valid();
+  }
+
+  static inline int bin_of(float x, float lo, float scale) {
+    const int b = (int)((x - lo) * scale);
+    return b < 0 ? 0 : (b >= kBins ? kBins - 1 : b);
+  }
+
+  void process(Task&& root) {
+    std::vector<Task> stack;
+    stack.push_back(std::move(root));
+    while (!stack.empty()) {
+      Task tk = std::move(stack.back());
+      stack.pop_back();
+      Task l, r;
+      if (!split(tk, l, r)) continue;
+      // hand large subtrees to other workers; keep going on the other one
+      if (threads_ > 1 && l.refs.size() + r.refs.size() > kParallelThreshold) {
+        spawn(std::move(r));
+        stack.push_back(std::move(l));
+      } else {
+        stack.push_back(std::move(r));
+        stack.push_back(std::move(l));
       }
     }
-    int bestAxis = -1, bestSplit = -1;
-    double bestCost = DBL_MAX;
+  }
+
+  // Splits the references of tk between two new children; returns false if the node became a leaf.
+  bool split(Task& tk, Task& L, Task& R) {
+    std::vector<Ref>& refs = tk.refs;
+    const size_t n = refs.size();
+    Node2& nd = nodes_[tk.node];
+    // ---- bounds of the boxes and of their centres ----
+    struct Bounds { Box3 box, cen; };
+    std::vector<Bounds> pb((size_t)std::max(1, threads_));
+    const int sl0 = chunked(n, [&](size_t b, size_t e, int s) {
+      Bounds w;
+      for (size_t i = b; i < e; ++i) {
+        const Ref& f = refs[i];
+        w.box.grow(f.lo, f.hi);
+        float c[3];
+        for (int a = 0; a < 3; ++a) c[a] = 0.5f * f.lo[a] + 0.5f * f.hi[a];   // not 0.5*(lo+hi): the sum can overflow near FLT_MAX
+        w.cen.grow(c, c);
+      }
+      pb[s] = w;
+    });
+    Bounds bb = pb[0];
+    for (int s = 1; s < sl0; ++s) { bb.box.grow(pb[s].box); bb.cen.grow(pb[s].cen); }
+    for (int a = 0; a < 3; ++a) { nd.lo[a] = bb.box.lo[a]; nd.hi[a] = bb.box.hi[a]; }
+    nd.left = 0;
+    nd.count = 1;
+    if (n <= 1) {
+      nd.first = n ? refs[0].prim : 0u;
+      return false;
+    }
+
+    // ---- object split: binned SAH over the centres ----
+    float oscale[3];
+    for (int a = 0; a < 3; ++a) { const float ext = bb.cen.hi[a] - bb.cen.lo[a]; oscale[a] = ext > 0.0f ? (float)kBins / ext : 0.0f; }
+    std::vector<std::array<Bin, 3 * kBins>> pbin((size_t)std::max(1, threads_));
+    const int sl1 = chunked(n, [&](size_t b, size_t e, int s) {
+      std::array<Bin, 3 * kBins>& bins = pbin[s];
+      for (Bin& x : bins) x = Bin();
+      for (size_t i = b; i < e; ++i) {
+        const Ref& f = refs[i];
+        for (int a = 0; a < 3; ++a) {
+          if (oscale[a] == 0.0f) continue;
+          Bin& bn = bins[a * kBins + bin_of(0.5f * f.lo[a] + 0.5f * f.hi[a], bb.cen.lo[a], oscale[a])];
+          bn.n++;
+          bn.box.grow(f.lo, f.hi);
+        }
+      }
+    });
+    for (int s = 1; s < sl1; ++s)
+      for (int k = 0; k < 3 * kBins; ++k) { pbin[0][k].n += pbin[s][k].n; pbin[0][k].box.grow(pbin[s][k].box); }
+    const std::array<Bin, 3 * kBins>& obins = pbin[0];
+    int oAxis = -1, oSplit = -1;
+    double oCost = DBL_MAX;
+    Box3 oL, oR;
     for (int a = 0; a < 3; ++a) {
-      if (scale[a] == 0.0f) continue;
-      double rarea[kBins]; uint32_t rcnt[kBins];
-      float l3[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, h3[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
-      uint32_t c = 0;
+      if (oscale[a] == 0.0f) continue;
+      Box3 rbox[kBins]; uint32_t rcnt[kBins];
+      Box3 acc; uint32_t c = 0;
       for (int b = kBins - 1; b > 0; --b) {
-        for (int k = 0; k < 3; ++k) { l3[k] = std::min(l3[k], bins[a][b].lo[k]); h3[k] = std::max(h3[k], bins[a][b].hi[k]); }
-        c += bins[a][b].n;
-        rarea[b] = c ? half_area(l3, h3) : 0.0;
-        rcnt[b] = c;
+        if (obins[a * kBins + b].n) acc.grow(obins[a * kBins + b].box);
+        c += obins[a * kBins + b].n;
+        rbox[b] = acc; rcnt[b] = c;
       }
-      for (int k = 0; k < 3; ++k) { l3[k] = FLT_MAX; h3[k] = -FLT_MAX; }
-      c = 0;
+      acc = Box3(); c = 0;
       for (int b = 0; b < kBins - 1; ++b) {
-        for (int k = 0; k < 3; ++k) { l3[k] = std::min(l3[k], bins[a][b].lo[k]); h3[k] = std::max(h3[k], bins[a][b].hi[k]); }
-        c += bins[a][b].n;
+        if (obins[a * kBins + b].n) acc.grow(obins[a * kBins + b].box);
+        c += obins[a * kBins + b].n;
         if (c == 0 || rcnt[b + 1] == 0) continue;
-        const double cost = half_area(l3, h3) * (double)c + rarea[b + 1] * (double)rcnt[b + 1];
-        if (cost < bestCost) { bestCost = cost; bestAxis = a; bestSplit = b; }
+        const double cost = acc.area() * (double)c + rbox[b + 1].area() * (double)rcnt[b + 1];
+        if (cost < oCost) { oCost = cost; oAxis = a; oSplit = b; oL = acc; oR = rbox[b + 1]; }
       }
     }
-    if (bestAxis < 0) {
-      mid = tk.begin + nd.count / 2;  // coincident centroids: halve the list
-    } else {
-      const int a = bestAxis;
-      auto it = std::partition(order_.begin() + tk.begin, order_.begin() + tk.end, [&](uint32_t pi) {
-        int b = (int)((prims_[pi].c[a] - clo[a]) * scale[a]);
-        b = b < 0 ? 0 : (b >= kBins ? kBins - 1 : b);
-        return b <= bestSplit;
-      });
-      mid = (uint32_t)(it - order_.begin());
-      if (mid == tk.begin || mid == tk.end) mid = tk.begin + nd.count / 2;
+
+    // ---- spatial split: only where the object split's sides overlap noticeably (relative to the root, Stich et al. eq. 3) ----
+    int sAxis = -1, sSplit = -1;
+    double sCost = DBL_MAX;
+    uint32_t sNL = 0, sNR = 0;
+    double splane_lo[3], swidth[3];
+    bool try_spatial = tk.budget > 0 && tk.depth < kMaxDepth2;
+    if (oAxis < 0) {   // coincident centres (the two triangles of a flat quad): the list is halved, both halves keep the box
+      oCost = bb.box.area() * (double)n;
+      try_spatial = try_spatial && bb.box.area() > alpha_ * root_area_;
     }
-    left = next_node_.fetch_add(2);
-    nd.left = left;
+    if (try_spatial && oAxis >= 0) {
+      Box3 ov;
+      for (int k = 0; k < 3; ++k) { ov.lo[k] = std::max(oL.lo[k], oR.lo[k]); ov.hi[k] = std::min(oL.hi[k], oR.hi[k]); }
+      try_spatial = ov.valid() && ov.area() > alpha_ * root_area_;
+    }
+    if (try_spatial) {
+      float sscale[3];
+      int longest = 0;
+      for (int a = 0; a < 3; ++a) {
+        const double ext = (double)bb.box.hi[a] - bb.box.lo[a];
+        splane_lo[a] = bb.box.lo[a];
+        swidth[a] = ext / kBins;
+        sscale[a] = ext > 0.0 && std::isfinite(ext) ? (float)(kBins / ext) : 0.0f;
+        if (ext > (double)bb.box.hi[longest] - bb.box.lo[longest]) longest = a;
+      }
+      // Small nodes (where most of the build's reference visits happen, and where a reference spans most of the bins)
+      // are only cut across their longest axis: a third of the clipping work
+      if (n <= (size_t)single_axis_below_)
+        for (int a = 0; a < 3; ++a) if (a != longest) sscale[a] = 0.0f;
+      const int sl2 = chunked(n, [&](size_t b, size_t e, int s) {
+        std::array<Bin, 3 * kBins>& bins = pbin[s];
+        for (Bin& x : bins) x = Bin();
+        for (size_t i = b; i < e; ++i) {
+          const Ref& f = refs[i];
+          for (int a = 0; a < 3; ++a) {
+            if (sscale[a] == 0.0f) continue;
+            const int b0 = bin_of(f.lo[a], bb.box.lo[a], sscale[a]), b1 = bin_of(f.hi[a], bb.box.lo[a], sscale[a]);
+            if (b0 == b1) {
+              Bin& bn = bins[a * kBins + b0];
+              bn.box.grow(f.lo, f.hi); bn.enter++; bn.leave++;
+              continue;
+            }
+            int first = -1, last = -1;
+            for (int k = b0; k <= b1; ++k) {
+              Box3 piece;
+              const double plo = k == b0 ? -DBL_MAX : splane_lo[a] + swidth[a] * k, phi = k == b1 ? DBL_MAX : splane_lo[a] + swidth[a] * (k + 1);
+              if (!clip_ref(f, a, plo, phi, piece)) continue;
+              bins[a * kBins + k].box.grow(piece);
+              if (first < 0) first = k;
+              last = k;
+            }
+            if (first < 0) { first = last = b0; bins[a * kBins + b0].box.grow(f.lo, f.hi); }   // (cannot happen: the primitive lies inside its box)
+            bins[a * kBins + first].enter++;
+            bins[a * kBins + last].leave++;
+          }
+        }
+      });
+      for (int s = 1; s < sl2; ++s)
+        for (int k = 0; k < 3 * kBins; ++k) {
+          pbin[0][k].enter += pbin[s][k].enter; pbin[0][k].leave += pbin[s][k].leave; pbin[0][k].box.grow(pbin[s][k].box);
+        }
+      const std::array<Bin, 3 * kBins>& sb = pbin[0];
+      for (int a = 0; a < 3; ++a) {
+        if (sscale[a] == 0.0f) continue;
+        Box3 rbox[kBins]; uint32_t rcnt[kBins];
+        Box3 acc; uint32_t c = 0;
+        for (int b = kBins - 1; b > 0; --b) {
+          acc.grow(sb[a * kBins + b].box);
+          c += sb[a * kBins + b].leave;
+          rbox[b] = acc; rcnt[b] = c;
+        }
+        acc = Box3(); c = 0;
+        for (int b = 0; b < kBins - 1; ++b) {
+          acc.grow(sb[a * kBins + b].box);
+          c += sb[a * kBins + b].enter;
+          if (c == 0 || rcnt[b + 1] == 0) continue;
+          const double cost = acc.area() * (double)c + rbox[b + 1].area() * (double)rcnt[b + 1];
+          if (cost < sCost) { sCost = cost; sAxis = a; sSplit = b; sNL = c; sNR = rcnt[b + 1]; }
+        }
+      }
+    }
+
+    // ---- partition ----
+    std::vector<Ref> left, right;
+    uint64_t used = 0;
+    bool done = false;
+    if (sAxis >= 0 && sCost < gain_ * oCost && (uint64_t)sNL + sNR - n <= tk.budget && sNL < n + (n >> 1) && sNR < n + (n >> 1)) {
+      const int a = sAxis;
+      const double pos = splane_lo[a] + swidth[a] * (sSplit + 1);
+      left.reserve(sNL); right.reserve(sNR);
+      for (const Ref& f : refs) {
+        if ((double)f.hi[a] <= pos) { left.push_back(f); continue; }
+        if ((double)f.lo[a] >= pos) { right.push_back(f); continue; }
+        Ref fl = f, fr = f;
+        Box3 bl, br;
+        const bool hl = clip_ref(f, a, -DBL_MAX, pos, bl), hr = clip_ref(f, a, pos, DBL_MAX, br);
+        if (hl) { for (int k = 0; k < 3; ++k) { fl.lo[k] = bl.lo[k]; fl.hi[k] = bl.hi[k]; } }
+        if (hr) { for (int k = 0; k < 3; ++k) { fr.lo[k] = br.lo[k]; fr.hi[k] = br.hi[k]; } }
+        if (hl && hr) { left.push_back(fl); right.push_back(fr); }
+        else if (hl) left.push_back(f);
+        else right.push_back(f);
+      }
+      if (!left.empty() && !right.empty() && left.size() + right.size() - n <= tk.budget) {
+        used = left.size() + right.size() - n;
+        n_spatial_.fetch_add(1);
+        done = true;
+      } else {
+        left.clear(); right.clear();
+      }
+    }
+    if (!done) {
+      left.reserve(n / 2 + 1); right.reserve(n / 2 + 1);
+      if (oAxis >= 0) {
+        const int a = oAxis;
+        for (const Ref& f : refs)
+          (bin_of(0.5f * f.lo[a] + 0.5f * f.hi[a], bb.cen.lo[a], oscale[a]) <= oSplit ? left : right).push_back(f);
+      }
+      if (left.empty() || right.empty()) {   // coincident centres: halve the list
+        left.assign(refs.begin(), refs.begin() + n / 2);
+        right.assign(refs.begin() + n / 2, refs.end());
+      }
+    }
+    std::vector<Ref>().swap(refs);
+    // the unused part of the budget goes down in proportion to the box areas on each side (where the loose boxes are)
+    uint64_t bl = 0, br = 0;
+    const uint64_t rest = tk.budget - used;
+    if (rest > 0) {
+      double al = 0.0, ar = 0.0;
+      for (const Ref& f : left) al += half_area(f.lo, f.hi);
+      for (const Ref& f : right) ar += half_area(f.lo, f.hi);
+      const double frac = (al + ar) > 0.0 && std::isfinite(al + ar) ? al / (al + ar) : 0.5;
+      bl = (uint64_t)((double)rest * frac);
+      if (bl > rest) bl = rest;
+      br = rest - bl;
+    }
+    const uint32_t li = next_node_.fetch_add(2);
+    nd.left = li;
+    L = Task{li, tk.depth + 1, bl, std::move(left)};
+    R = Task{li + 1, tk.depth + 1, br, std::move(right)};
     return true;
   }
 
-  void process(const Task& root) {
-    std::vector<Task> stack;
-    stack.push_back(root);
-    while (!stack.empty()) {
-      Task tk = stack.back();
-      stack.pop_back();
-      uint32_t mid, left;
-      if (!split(tk, mid, left)) continue;
-      Task l{left, tk.begin, mid}, r{left + 1, mid, tk.end};
-      // hand large subtrees to other workers; keep going on the other one
-      if (threads_ > 1 && (tk.end - tk.begin) > kParallelThreshold) {
-        spawn(r);
-        stack.push_back(l);
-      } else {
-        stack.push_back(r);
-        stack.push_back(l);
-      }
-    }
-  }
-
-  const std::vector<Prim>& prims_;
-  std::vector<uint32_t>& order_;
+  const float* verts_;
+  const std::vector<PrimRef>& prims_;
+  float pad_;
   std::vector<Node2>& nodes_;
   int threads_;
+  double alpha_;
+  int single_axis_below_ = 32;
+  double gain_;   // a spatial split must cost less than gain_ x the best object split
+  double root_area_ = 1.0;
   std::atomic<uint32_t> next_node_{1};
   std::atomic<int> outstanding_{0};
+  std::atomic<uint64_t> n_spatial_{0};
   std::mutex mu_;
   std::condition_variable cv_;
   std::vector<Task> tasks_;
 };
+
+// Leaves of the binary tree hold one reference each (Node2::first = its primitive while building). This pass lays the
+// references out in depth-first order and gives every node the range of its subtree: first / count into `order`.
+static void assign_ranges(std::vector<Node2>& nodes, std::vector<uint32_t>& order) {
+  order.clear();
+  std::vector<std::pair<uint32_t, bool>> stack;   // (node, children done)
+  stack.push_back({0u, false});
+  while (!stack.empty()) {
+    auto [i, after] = stack.back();
+    stack.pop_back();
+    Node2& nd = nodes[i];
+    if (nd.left == 0) {
+      const uint32_t prim = nd.first;
+      nd.first = (uint32_t)order.size();
+      nd.count = 1;
+      order.push_back(prim);
+    } else if (!after) {
+      stack.push_back({i, true});
+      stack.push_back({nd.left + 1, false});
+      stack.push_back({nd.left, false});
+    } else {
+      nd.first = nodes[nd.left].first;
+      nd.count = nodes[nd.left].count + nodes[nd.left + 1].count;
+    }
+  }
+}
 
 // decision record of the collapse DP
 enum : uint8_t { D_LEAF = 0, D_INTERNAL = 1, D_DISTRIBUTE = 2 };
@@ -251,8 +513,10 @@ static void pair_triangles(const float* verts, const std::vector<uint32_t>& acti
       for (size_t s = ek[e] & mask;; s = (s + 1) & mask) {
         const Slot sl = table[s];
         if (sl.tri == 0xFFFFFFFFu && sl.tag == 0u) break;            // empty: this edge was never entered
+        // both ways round: a degenerate triangle (two equal positions) "shares two vertices" with any triangle through
+        // that position, but the record has room for ONE vertex of the second triangle that the first does not have
         if (sl.tag == tag && sl.tri != 0xFFFFFFFFu && sl.tri != i && partner[sl.tri] == 0xFFFFFFFFu &&
-            shared_vertices(verts + (size_t)sl.tri * 9, t) >= 2) {
+            shared_vertices(verts + (size_t)sl.tri * 9, t) >= 2 && shared_vertices(t, verts + (size_t)sl.tri * 9) >= 2) {
           partner[sl.tri] = i;
           partner[i] = sl.tri;
           paired = true;
@@ -284,7 +548,8 @@ void build_bvh8(const float* verts, uint32_t n, Bvh8& out, int num_threads, int 
   out.prims.clear();
   out.num_pairs = 0;
   out.max_depth = 0;
-  if (const char* e = getenv("PT_BVH_PAIRS")) pair_mode = atoi(e);   // tuning runs
+  if (pair_mode < 0)
+    if (const char* e = getenv("PT_BVH_PAIRS")) pair_mode = atoi(e);   // tuning runs only: an explicit flag of the caller is never overridden
   // auto: an unpaired hierarchy costs ~56 bytes per triangle (48-byte record + its share of the nodes)
   out.paired = pair_mode > 0 || (pair_mode < 0 && (double)n * 56.0 > 224.0 * 1024.0 * 1024.0);
 
@@ -322,7 +587,6 @@ void build_bvh8(const float* verts, uint32_t n, Bvh8& out, int num_threads, int 
   std::vector<uint32_t> partner;
   if (out.paired) pair_triangles(verts, order, n, partner);
   else partner.assign(n, 0xFFFFFFFFu);
-  struct PrimRef { uint32_t a, b; };
   std::vector<PrimRef> refs;
   refs.reserve(order.size());
   for (uint32_t i : order) {
@@ -330,10 +594,11 @@ void build_bvh8(const float* verts, uint32_t n, Bvh8& out, int num_threads, int 
     else if (partner[i] > i) refs.push_back({i, partner[i]});
   }
   const uint32_t np = (uint32_t)refs.size();
-  std::vector<Prim> prims(np);
+  std::vector<Ref> boxes(np);
   std::vector<float> weight(np);      // SAH weight of a record: one triangle test, or two that share their set-up
   for (uint32_t k = 0; k < np; ++k) {
-    Prim& p = prims[k];
+    Ref& p = boxes[k];
+    p.prim = k;
     for (int a = 0; a < 3; ++a) { p.lo[a] = FLT_MAX; p.hi[a] = -FLT_MAX; }
     for (int h = 0; h < 2; ++h) {
       const uint32_t t = h ? refs[k].b : refs[k].a;
@@ -344,18 +609,28 @@ void build_bvh8(const float* verts, uint32_t n, Bvh8& out, int num_threads, int 
         p.hi[a] = std::max(p.hi[a], std::max(v[a], std::max(v[3 + a], v[6 + a])));
       }
     }
-    for (int a = 0; a < 3; ++a) {
-      p.c[a] = 0.5f * p.lo[a] + 0.5f * p.hi[a];   // not 0.5*(lo+hi): the sum can overflow for |coordinates| near FLT_MAX
-      p.lo[a] -= pad;
-      p.hi[a] += pad;
-    }
+    for (int a = 0; a < 3; ++a) { p.lo[a] -= pad; p.hi[a] += pad; }
     weight[k] = refs[k].b == 0xFFFFFFFFu ? 1.0f : 1.6f;
     if (refs[k].b != 0xFFFFFFFFu) out.num_pairs++;
   }
-  order.resize(np);
-  for (uint32_t k = 0; k < np; ++k) order[k] = k;
+  // Spatial splits may add up to split_budget x the primitive count in references; a node is considered for one when the
+  // overlap of its best object split exceeds split_alpha x the root's area, and the split is taken when it costs less than
+  // split_gain x the object split. Chosen on the CPU walker (tools/bvh_cpu_quality.py, secondary rays): on street_hard
+  // 69.8 nodes + 178.8 triangles per ray without splits, 37.7 + 19.1 with these values (gain 1.0: 35.2 + 19.9, but it costs
+  // the regular scenes 1-2 % more node visits; gain 0.9 leaves atrium / street within 0.1 %; gain 0.75: 64 + 26.5).
+  // PT_BVH_SPLIT_BUDGET / _ALPHA / _GAIN override them in tuning runs (budget 0 = object splits only).
+  double split_budget = 1.0, split_alpha = 1e-6, split_gain = 0.9;
+  if (const char* e = getenv("PT_BVH_SPLIT_BUDGET")) { const double v = atof(e); if (v >= 0.0 && v <= 4.0) split_budget = v; }
+  if (const char* e = getenv("PT_BVH_SPLIT_ALPHA")) { const double v = atof(e); if (v >= 0.0) split_alpha = v; }
+  if (const char* e = getenv("PT_BVH_SPLIT_GAIN")) { const double v = atof(e); if (v > 0.0) split_gain = v; }
   std::vector<Node2> n2;
-  Builder2(prims, order, n2, num_threads).run();
+  {
+    SplitBuilder sb(verts, refs, pad, n2, num_threads, split_alpha, split_gain);
+    sb.run(std::move(boxes), (uint64_t)((double)np * split_budget));
+    out.spatial_splits = sb.spatial_splits();
+  }
+  assign_ranges(n2, order);
+  out.num_references = order.size();
   const uint32_t nn = (uint32_t)n2.size();
 
   // ---- SAH-optimal collapse (dynamic programme over "up to i roots", i = 1..7) ----
@@ -406,7 +681,7 @@ void build_bvh8(const float* verts, uint32_t n, Bvh8& out, int num_threads, int 
   struct Work { uint32_t n2; uint32_t out; uint32_t depth; };
   std::deque<Work> queue;
   out.nodes.reserve(nn / 4 + 16);
-  if (out.paired) out.prims.reserve(np); else out.tris.reserve(np);
+  if (out.paired) out.prims.reserve(order.size()); else out.tris.reserve(order.size());
   out.nodes.emplace_back();
   queue.push_back({0, 0, 1});
   std::vector<ChildRef> kids;
@@ -519,11 +794,18 @@ void build_bvh8(const float* verts, uint32_t n, Bvh8& out, int num_threads, int 
         queue.push_back({cr.n2, node.child_base + ninternal, w.depth + 1});
         ninternal++;
       } else {
-        const uint32_t cnt = ch.count;  // 1..3
+        // 1..3 references; two pieces of one primitive that a spatial split sent into the same leaf need one record only
+        uint32_t uniq[PT_BVH8_MAX_LEAF_TRIS], cnt = 0;
+        for (uint32_t i = 0; i < ch.count; ++i) {
+          const uint32_t pk = order[ch.first + i];
+          bool seen = false;
+          for (uint32_t j = 0; j < cnt; ++j) seen = seen || uniq[j] == pk;
+          if (!seen) uniq[cnt++] = pk;
+        }
         const uint32_t unary = cnt == 1 ? 1u : (cnt == 2 ? 3u : 7u);
         node.meta[s] = (uint8_t)((unary << 5) | tri_off);
         for (uint32_t i = 0; i < cnt; ++i) {
-          const PrimRef& pr = refs[order[ch.first + i]];
+          const PrimRef& pr = refs[uniq[i]];
           const float* v = verts + (size_t)pr.a * 9;
           if (!out.paired) {
             PtTriRecord t3;

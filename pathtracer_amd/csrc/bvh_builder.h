@@ -22,11 +22,14 @@ struct Bvh8 {
   float lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
   double build_ms = 0.0;
   double sah_cost = 0.0;
+  uint64_t num_references = 0;     // leaf references of the binary tree: primitives + the duplicates spatial splits made
+  uint64_t spatial_splits = 0;     // nodes of the binary tree that were split by a plane instead of by partitioning objects
 };
 
 // verts: 9 floats per triangle (v0,v1,v2 world space); triangle i gets global id i.
 // Edge-sharing triangles are paired into primitives first (greedy, by exact vertex positions). Binned-SAH binary BVH
-// over the primitives (single-primitive leaves) -> SAH-optimal collapse to 8-wide nodes with <=3 records per
+// with spatial splits (SBVH: a long or diagonal primitive may be referenced from several leaves, each with the tight box
+// of its piece; single-reference leaves) -> SAH-optimal collapse to 8-wide nodes with <=3 records per
 // leaf -> octant-ordered child slots -> 8-bit quantisation (conservative, padded by a scene-relative epsilon).
 // pair_mode: 0 = triangle records, 1 = pair edge-sharing triangles, -1 = decide by size (pairs once the unpaired hierarchy
 // would exceed the Infinity Cache: measured +9.5 % on 10.5 M triangles, -4 % on 262 k).

@@ -11,14 +11,10 @@ struct DeviceScene {
   const uint4* nodes = nullptr;        // 5 x uint4 per 80-byte BVH8 node
   const uint4* tris = nullptr;         // leaf records: 48-byte triangles, or (paired) 64-byte records of one triangle or an edge-sharing pair
   bool paired = false;                 // record format of `tris` (csrc/bvh8.h)
-  const uint4* prim_data = nullptr;    // per global triangle id: i0,i1,i2 (global vertex ids), instance id
-  const float4* vertex_normal = nullptr;
+  const uint4* prim_data = nullptr;    // per global triangle id: i0,i1,i2 (global vertex ids), instance id (read with the material extension only)
   const float4* prim_shade = nullptr;  // 4 x float4 per global triangle id: {n0, instance id bits}, {n1, colour r}, {n2, colour g}, {emission, colour b} (colour = decoded unorm, alpha unused):
                                        // everything ClosestHit loads, in ONE 64-byte record (one dependent fetch instead of three)
   const float2* vertex_uv = nullptr;
-  const uint32_t* instance_material = nullptr;
-  const float4* materials = nullptr;   // emission.xyz, rgba8 bits
-  const float4* instance_mat4 = nullptr; // materials[instance_material[i]] per instance
   const float4* instance_ext = nullptr;  // material extension per instance (roughness, metallic, pattern scale, pattern | ggx << 8); null = none
   float scene_mag = 0.0f;              // largest |coordinate| of the active triangles (overflow guard of the box test)
   uint32_t num_nodes = 0;              // BVH8 nodes in `nodes`
@@ -115,6 +111,7 @@ void launch_extend_packet(const DeviceScene& sc, const float4* ray_o, const floa
                           uint32_t* work_cursor, int blocks, hipStream_t s, const float4* primary_gen);
 int extend_packet_occupancy_blocks(uint32_t stack_entries, bool paired);
 size_t extend_lds_bytes(uint32_t lds_entries_total, uint32_t top_nodes);
+int extend_ns_private_bytes(bool defer, bool paired, size_t* bytes_out);   // 0 = ok; private-segment bytes of the k_extend_ns instantiation
 int extend_occupancy_blocks(uint32_t lds_entries_total, uint32_t top_nodes, bool defer, bool paired, bool no_private_segment = false);
 
 }  // namespace pt

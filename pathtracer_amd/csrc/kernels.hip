@@ -64,6 +64,26 @@ __device__ __forceinline__ void st_stream(uint32_t* p, uint32_t v) {
 #endif
 }
 
+// PT_DEBUG_BOUNDS=1 (make debug): every queue append checks its slot against the queue's capacity and traps with a message
+// instead of writing past the buffer. The slots come from atomicAdd on ONE counter word per queue and at most one append
+// per path per bounce reaches it, so slot < paths-in-batch <= capacity holds by construction; the check exists because
+// an experiment that broke that invariant (round 2: the appends spread over several counter words)
+// turned into out-of-bounds stores here and faulted the GPU.
+#ifndef PT_DEBUG_BOUNDS
+#define PT_DEBUG_BOUNDS 0
+#endif
+#if PT_DEBUG_BOUNDS
+#define PT_CHECK_SLOT(slot, cap, what)                                                                                   \
+  do {                                                                                                                   \
+    if ((slot) >= (cap)) {                                                                                               \
+      printf("pt: %s slot %u >= capacity %u (block %u thread %u)\n", what, (unsigned)(slot), (unsigned)(cap), blockIdx.x, threadIdx.x); \
+      __builtin_trap();                                                                                                  \
+    }                                                                                                                    \
+  } while (0)
+#else
+#define PT_CHECK_SLOT(slot, cap, what) do { } while (0)
+#endif
+
 // Wave-aggregated queue append: one atomic per wave. Must be called by all 64 lanes convergently.
 __device__ __forceinline__ uint32_t wave_append(uint32_t* counter, bool pred) {
   const unsigned long long mask = __ballot(pred);
@@ -107,9 +127,6 @@ __device__ __forceinline__ void block_append2(BlockAppendLds& L, int parity, uin
       run += c;
     }
     L.base[parity][q] = run ? atomicAdd(q == 0u ? counter0 : counter1, run) : 0u;
-#ifdef PT_EXP_SHADE_EXTRA_ATOMIC   // experiment: a second, dependent returning atomic per append: is k_shade bound by that round trip?
-    L.base[parity][q] += atomicAdd(counter0 + 64 * 40 + q * 64, L.base[parity][q] & 1u) & 0u;
-#endif
   }
   __syncthreads();
   const unsigned long long below = (1ull << lane) - 1ull;
@@ -457,8 +474,8 @@ __global__ void __launch_bounds__(PT_SHADE_THREADS, PT_SHADE_MIN_WAVES) k_shade(
                                                float4* __restrict__ ray_d_out, uint32_t* __restrict__ qid_out,
                                                float4* __restrict__ sky_o, float4* __restrict__ sky_d,
                                                uint32_t* __restrict__ counters, int bounce, uint32_t w, uint32_t h,
-                                               uint32_t first_sample, uint32_t russian_roulette, uint32_t spp) {
-  // spp: samples per pixel of the batch (path id = pixel * spp + sample)
+                                               uint32_t first_sample, uint32_t russian_roulette, uint32_t spp, uint32_t capacity) {
+  // spp: samples per pixel of the batch (path id = pixel * spp + sample); capacity: entries of every queue (PT_DEBUG_BOUNDS)
   // FUSED (only at bounce 0): no k_generate ran; the ray is recomputed from the path index, T = 1, L = 0 and the
   // RNG counter after the jitter are constants, and this kernel (k_sky for sky misses) gives st_L its first value
   const uint32_t n = counters[CTR_AT(CTR_QCOUNT0 + bounce)];
@@ -604,11 +621,13 @@ __global__ void __launch_bounds__(PT_SHADE_THREADS, PT_SHADE_MIN_WAVES) k_shade(
     uint32_t slot, sslot;
     block_append2(s_app, parity, &counters[CTR_AT(CTR_QCOUNT0 + bounce + 1)], want_ray, &counters[CTR_AT(CTR_SKY)], want_sky, slot, sslot);
     if (want_ray) {
+      PT_CHECK_SLOT(slot, capacity, "k_shade ray queue");
       st_stream(ray_o_out + slot, make_float4(newOrigin.x, newOrigin.y, newOrigin.z, 0.001f));  // TMin 0.001 (:127)
       st_stream(ray_d_out + slot, make_float4(newDir.x, newDir.y, newDir.z, 10000.0f));
       st_stream(qid_out + slot, pid);
     }
     if (want_sky) {
+      PT_CHECK_SLOT(sslot, capacity, "k_shade sky queue");
       st_stream(sky_o + sslot, make_float4(origin.x, origin.y, origin.z, __uint_as_float(pid)));
       st_stream(sky_d + sslot, make_float4(dir.x, dir.y, dir.z, FUSED ? 1.0f : 0.0f));   // w != 0: T = 1 and L = 0, not in memory
     }
@@ -667,7 +686,7 @@ __global__ void __launch_bounds__(PT_SHADE_THREADS) k_ao_primary(PtRtConsts c, c
                                                                  const float4* __restrict__ ray_d, const float4* __restrict__ hits,
                                                                  float4* __restrict__ st_L, uint32_t* __restrict__ qid_out,
                                                                  float4* __restrict__ sky_o, float4* __restrict__ sky_d,
-                                                                 uint32_t* __restrict__ counters) {
+                                                                 uint32_t* __restrict__ counters, uint32_t capacity) {
   const uint32_t n = counters[CTR_AT(CTR_QCOUNT0)];
   __shared__ BlockAppendLds s_app;
   const uint32_t lane = threadIdx.x & 63u;
@@ -688,8 +707,9 @@ __global__ void __launch_bounds__(PT_SHADE_THREADS) k_ao_primary(PtRtConsts c, c
     }
     uint32_t slot, sslot;
     block_append2(s_app, parity, &counters[CTR_AT(CTR_AO_HITS)], want_hit, &counters[CTR_AT(CTR_SKY)], want_sky, slot, sslot);
-    if (want_hit) qid_out[slot] = j;
+    if (want_hit) { PT_CHECK_SLOT(slot, capacity, "k_ao_primary hit list"); qid_out[slot] = j; }
     if (want_sky) {
+      PT_CHECK_SLOT(sslot, capacity, "k_ao_primary sky queue");
       const float4 o = ray_o[j], d = ray_d[j];
       sky_o[sslot] = make_float4(o.x, o.y, o.z, __uint_as_float(j));
       sky_d[sslot] = make_float4(d.x, d.y, d.z, 0.0f);
@@ -985,6 +1005,19 @@ void launch_extend(const DeviceScene& sc, const float4* ray_o, const float4* ray
 #undef PT_LAUNCH_EXTEND
 }
 
+// pt_trace_rays_device_noalloc may only launch k_extend_ns if that kernel has NO private segment (register spills, stack
+// arrays): with one, the HIP runtime allocates scratch memory at launch, behind the caller's back. Nothing but the compiler
+// decides that, so it is asked here: bytes of private segment of the instantiation that would be launched.
+int extend_ns_private_bytes(bool defer, bool paired, size_t* bytes_out) {
+  hipFuncAttributes a;
+  const void* f = paired ? (defer ? reinterpret_cast<const void*>(&k_extend_ns<false, true, true>) : reinterpret_cast<const void*>(&k_extend_ns<false, false, true>))
+                         : (defer ? reinterpret_cast<const void*>(&k_extend_ns<false, true, false>) : reinterpret_cast<const void*>(&k_extend_ns<false, false, false>));
+  const hipError_t e = hipFuncGetAttributes(&a, f);
+  if (e != hipSuccess) return (int)e;
+  *bytes_out = a.localSizeBytes;
+  return 0;
+}
+
 int extend_packet_occupancy_blocks(uint32_t stack_entries, bool paired) {
   int nb = 0;
   const size_t lds = (size_t)stack_entries * 4u * sizeof(uint2);
@@ -1016,7 +1049,8 @@ void launch_shade(const PtRtConsts& c, const DeviceScene& sc, const WavefrontBuf
 #define PT_LAUNCH_SHADE(E, F)                                                                                               \
   hipLaunchKernelGGL((k_shade<E, F>), dim3((unsigned)g), dim3(PT_SHADE_THREADS), 0, s, c, sc, wb.ray_o[in], wb.ray_d[in],   \
                      bounce == 0 ? (const uint32_t*)nullptr : wb.qid[in], wb.hits, wb.st_T, wb.st_L, wb.ray_o[out], wb.ray_d[out], \
-                     wb.qid[out], wb.sky_o, wb.sky_d, wb.counters, bounce, w, h, first_sample, russian_roulette ? 1u : 0u, (uint32_t)(max_paths / ((uint64_t)w * h)))
+                     wb.qid[out], wb.sky_o, wb.sky_d, wb.counters, bounce, w, h, first_sample, russian_roulette ? 1u : 0u, (uint32_t)(max_paths / ((uint64_t)w * h)), \
+                     (uint32_t)(wb.capacity > 0xFFFFFFFFull ? 0xFFFFFFFFull : wb.capacity))
   if (fused_primary && bounce == 0) {
     if (sc.instance_ext) PT_LAUNCH_SHADE(true, true); else PT_LAUNCH_SHADE(false, true);
   } else {
@@ -1030,7 +1064,7 @@ void launch_ao_primary(const PtRtConsts& c, const WavefrontBuffers& wb, uint64_t
   const uint64_t cap = (uint64_t)cfg.num_cus * 8u;
   g = g > cap ? cap : (g < 1 ? 1 : g);
   hipLaunchKernelGGL(k_ao_primary, dim3((unsigned)g), dim3(PT_SHADE_THREADS), 0, s, c, wb.ray_o[0], wb.ray_d[0], wb.hits, wb.st_L, wb.qid[0],
-                     wb.sky_o, wb.sky_d, wb.counters);
+                     wb.sky_o, wb.sky_d, wb.counters, (uint32_t)(wb.capacity > 0xFFFFFFFFull ? 0xFFFFFFFFull : wb.capacity));
 }
 
 void launch_ao_rays(const PtRtConsts& c, const DeviceScene& sc, const WavefrontBuffers& wb, float4* ao_o, float4* ao_d, uint32_t w, uint32_t h,

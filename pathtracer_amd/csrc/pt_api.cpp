@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "../../include/pt_api.h"
+#include "../../include/pt_api_tuning.h"
 #ifndef PT_NODE_STRIDE_U4
 #define PT_NODE_STRIDE_U4 5
 #endif
@@ -337,7 +338,9 @@ int calibrate_primary_kernel(pt_ctx* ctx, const PtRtConsts& consts, uint32_t wid
     PT_HIP(hipEventElapsedTime(&ctx->packet_cal_ms[i], ev[i].first, ev[i].second));
     ctx->event_pool.push_back(ev[i]);
   }
-  ctx->packet_choice = ctx->packet_cal_ms[1] <= ctx->packet_cal_ms[0] ? 1 : 0;
+  // the packet kernel must win by 5 %: within the timing noise the general kernel is kept, so the choice (and with it the
+  // performance of later calls) is reproducible from run to run
+  ctx->packet_choice = ctx->packet_cal_ms[1] <= 0.95f * ctx->packet_cal_ms[0] ? 1 : 0;
   ctx->packet_choice_w = width;
   ctx->packet_choice_h = height;
   return PT_OK;
@@ -441,49 +444,51 @@ int pt_set_option(pt_ctx* ctx, int option, int64_t value) {
       if (value != 0 && value != 1) return ctx->fail(PT_ERR_UNSUPPORTED, "sky mode must be 0 (ray-march on every miss) or 1 (direction LUT)");
       ctx->sky_mode = (int)value;
       return PT_OK;
-    case PT_OPT_EXTEND_FETCH_MIN:
-      if (value < 1 || value > 64) return ctx->fail(PT_ERR_INVALID_ARG, "fetch_min must be 1..64");
-      ctx->cfg.fetch_min = (uint32_t)value;
-      return PT_OK;
-    case PT_OPT_EXTEND_POSTPONE_PCT:
-      if (value < 0 || value > 100) return ctx->fail(PT_ERR_INVALID_ARG, "postpone_pct must be 0..100");
-      ctx->cfg.postpone_pct = (uint32_t)value;
-      return PT_OK;
-    case PT_OPT_EXTEND_LDS_STACK:
-      if (value < 1 || value > 128) return ctx->fail(PT_ERR_INVALID_ARG, "LDS stack entries must be 1..128");
-      ctx->cfg.lds_stack_entries = (uint32_t)value;
-      if (ctx->has_scene)
-        ctx->cfg.extend_blocks = extend_grid(ctx);
-      return PT_OK;
-    case PT_OPT_EXTEND_DEFER:
-      if (value < 0 || value > 16) return ctx->fail(PT_ERR_INVALID_ARG, "deferred-triangle queue must be 0..16 entries");
-      ctx->cfg.defer_entries = (uint32_t)value;
-      if (ctx->has_scene)
-        ctx->cfg.extend_blocks = extend_grid(ctx);
-      return PT_OK;
     case PT_OPT_PRIMARY_PACKET: ctx->primary_packet = value < 0 ? 0 : (value > 2 ? 2 : (int)value); return PT_OK;
     case PT_OPT_FUSED_PRIMARY:
       if (value != 0 && value != 1) return ctx->fail(PT_ERR_INVALID_ARG, "PT_OPT_FUSED_PRIMARY must be 0 or 1");
       ctx->fused_primary = value != 0;
       return PT_OK;
-    case PT_OPT_EXTEND_CONTINUE_PCT:
+    default: return ctx->fail(PT_ERR_INVALID_ARG, "unknown option (the traversal kernel's tuning knobs go through pt_debug_set_tuning, include/pt_api_tuning.h)");
+  }
+}
+
+// include/pt_api_tuning.h: the schedule knobs of k_extend (no counterpart in the reference; none changes a hit record)
+int pt_debug_set_tuning(pt_ctx* ctx, int knob, int64_t value) {
+  PT_REQUIRE_CTX();
+  switch (knob) {
+    case PT_TUNE_EXTEND_FETCH_MIN:
+      if (value < 1 || value > 64) return ctx->fail(PT_ERR_INVALID_ARG, "fetch_min must be 1..64");
+      ctx->cfg.fetch_min = (uint32_t)value;
+      return PT_OK;
+    case PT_TUNE_EXTEND_POSTPONE_PCT:
+      if (value < 0 || value > 100) return ctx->fail(PT_ERR_INVALID_ARG, "postpone_pct must be 0..100");
+      ctx->cfg.postpone_pct = (uint32_t)value;
+      return PT_OK;
+    case PT_TUNE_EXTEND_CONTINUE_PCT:
       if (value < 0 || value > 100) return ctx->fail(PT_ERR_INVALID_ARG, "continue_pct must be 0..100");
       ctx->cfg.continue_pct = (uint32_t)value;
       return PT_OK;
-    case PT_OPT_EXTEND_TOP_NODES:
+    case PT_TUNE_EXTEND_LDS_STACK:
+      if (value < 1 || value > 128) return ctx->fail(PT_ERR_INVALID_ARG, "LDS stack entries must be 1..128");
+      ctx->cfg.lds_stack_entries = (uint32_t)value;
+      break;
+    case PT_TUNE_EXTEND_DEFER:
+      if (value < 0 || value > 16) return ctx->fail(PT_ERR_INVALID_ARG, "deferred-triangle queue must be 0..16 entries");
+      ctx->cfg.defer_entries = (uint32_t)value;
+      break;
+    case PT_TUNE_EXTEND_TOP_NODES:
       if (value < 0 || value > 1024) return ctx->fail(PT_ERR_INVALID_ARG, "top nodes kept in LDS must be 0..1024");
       ctx->cfg.top_nodes = (uint32_t)value;
-      if (ctx->has_scene)
-        ctx->cfg.extend_blocks = extend_grid(ctx);
-      return PT_OK;
-    case PT_OPT_EXTEND_BLOCKS_PER_CU:
+      break;
+    case PT_TUNE_EXTEND_BLOCKS_PER_CU:
       if (value < 0 || value > 16) return ctx->fail(PT_ERR_INVALID_ARG, "blocks per CU must be 0..16");
       ctx->cfg.extend_blocks_per_cu = (int)value;
-      if (ctx->has_scene)
-        ctx->cfg.extend_blocks = extend_grid(ctx);
-      return PT_OK;
-    default: return ctx->fail(PT_ERR_INVALID_ARG, "unknown option");
+      break;
+    default: return ctx->fail(PT_ERR_INVALID_ARG, "unknown tuning knob");
   }
+  if (ctx->has_scene) ctx->cfg.extend_blocks = extend_grid(ctx);   // these four change the kernel's LDS footprint or grid
+  return PT_OK;
 }
 
 int pt_scene_create(pt_ctx* ctx, const PtMeshDesc* meshes, uint32_t num_meshes, const PtInstanceDesc* instances,
@@ -506,19 +511,15 @@ int pt_scene_create(pt_ctx* ctx, const PtMeshDesc* meshes, uint32_t num_meshes, 
   ctx->ds = DeviceScene();
 
   uint4 *d_nodes, *d_tris, *d_prim;
-  float4 *d_vn, *d_mat, *d_imat, *d_ps;
+  float4* d_ps;
   float2* d_uv;
-  uint32_t* d_im;
   if ((rc = dev_alloc(ctx, &d_nodes, bvh.nodes.size() * PT_NODE_STRIDE_U4, &ctx->scene_allocs))) return rc;
   if ((rc = dev_alloc(ctx, &d_tris, bvh.num_records() * bvh.record_bytes() / 16, &ctx->scene_allocs))) return rc;
   if ((rc = dev_alloc(ctx, &d_prim, (size_t)fs.num_triangles(), &ctx->scene_allocs))) return rc;
-  if ((rc = dev_alloc(ctx, &d_vn, (size_t)fs.num_vertices(), &ctx->scene_allocs))) return rc;
   if ((rc = dev_alloc(ctx, &d_uv, (size_t)fs.num_vertices(), &ctx->scene_allocs))) return rc;
-  if ((rc = dev_alloc(ctx, &d_im, fs.instance_material.size(), &ctx->scene_allocs))) return rc;
-  if ((rc = dev_alloc(ctx, &d_mat, (size_t)num_materials, &ctx->scene_allocs))) return rc;
-  if ((rc = dev_alloc(ctx, &d_imat, fs.instance_material.size(), &ctx->scene_allocs))) return rc;
   if ((rc = dev_alloc(ctx, &d_ps, (size_t)fs.num_triangles() * 4, &ctx->scene_allocs))) return rc;
-  // LoadInstanceData + LoadMaterialData (Common.hlsl:75-100) resolved once per instance: one gather per hit, not two
+  // LoadInstanceData + LoadMaterialData (Common.hlsl:75-100) resolved once per instance on the host; the vertex normals,
+  // instance -> material table and materials themselves only live in the ClosestHit rows below (no kernel reads them)
   std::vector<float> inst_mat(fs.instance_material.size() * 4);
   for (size_t i = 0; i < fs.instance_material.size(); ++i)
     memcpy(&inst_mat[4 * i], &fs.materials[4 * (size_t)fs.instance_material[i]], 16);
@@ -536,11 +537,7 @@ int pt_scene_create(pt_ctx* ctx, const PtMeshDesc* meshes, uint32_t num_meshes, 
 #endif
   PT_HIP(up(d_tris, bvh.records(), bvh.num_records() * bvh.record_bytes()));
   PT_HIP(up(d_prim, fs.prim_data.data(), fs.prim_data.size() * 4));
-  PT_HIP(up(d_vn, fs.vertex_normal.data(), fs.vertex_normal.size() * 4));
   PT_HIP(up(d_uv, fs.vertex_uv.data(), fs.vertex_uv.size() * 4));
-  PT_HIP(up(d_im, fs.instance_material.data(), fs.instance_material.size() * 4));
-  PT_HIP(up(d_mat, fs.materials.data(), fs.materials.size() * 4));
-  PT_HIP(up(d_imat, inst_mat.data(), inst_mat.size() * 4));
   {
     // ClosestHit record per triangle (PathTracing.hlsl:16-38 reads instance -> material, 3 indices, 3 x VertexData: four
     // dependent fetches; here they are resolved at upload into one 64-byte row)
@@ -571,11 +568,7 @@ int pt_scene_create(pt_ctx* ctx, const PtMeshDesc* meshes, uint32_t num_meshes, 
   ctx->ds.paired = bvh.paired;
   ctx->num_records = bvh.num_records();
   ctx->ds.prim_data = d_prim;
-  ctx->ds.vertex_normal = d_vn;
   ctx->ds.vertex_uv = d_uv;
-  ctx->ds.instance_material = d_im;
-  ctx->ds.materials = d_mat;
-  ctx->ds.instance_mat4 = d_imat;
   ctx->ds.prim_shade = d_ps;
   ctx->ds.num_nodes = (uint32_t)bvh.nodes.size();
   for (int a = 0; a < 3; ++a) ctx->ds.scene_mag = std::max(ctx->ds.scene_mag, std::max(std::fabs(bvh.lo[a]), std::fabs(bvh.hi[a])));
@@ -786,11 +779,6 @@ int pt_render(pt_ctx* ctx, const PtRtConsts* consts, uint32_t width, uint32_t he
     spb = (spb + 1) / 2;
   }
 
-  std::pair<hipEvent_t, hipEvent_t> rev{nullptr, nullptr};
-  if (ctx->time_kernels) {
-    rev = get_event_pair(ctx);
-    PT_HIP(hipEventRecord(rev.first, ctx->stream));
-  }
   const uint32_t bounces = consts->myMaxRecursionDepth + 1;  // inclusive loop bound (PathTracing.hlsl:68)
   const bool use_skyview = ctx->sky_mode == 1 && consts->mySampleSky && skyview_valid_for(*consts);
   if (use_skyview) launch_skyview_lut(*consts, ctx->lut, ctx->skyview, ctx->stream);   // 64 Ki texels, a few microseconds
@@ -803,6 +791,11 @@ int pt_render(pt_ctx* ctx, const PtRtConsts* consts, uint32_t width, uint32_t he
       if ((rc = calibrate_primary_kernel(ctx, *consts, width, height, first_sample, std::max<uint32_t>(1u, k0))) != PT_OK) return rc;
     }
     packet = ctx->packet_choice == 1;
+  }
+  std::pair<hipEvent_t, hipEvent_t> rev{nullptr, nullptr};
+  if (ctx->time_kernels) {   // after the one-off timing above: render_ms is the render, not the calibration
+    rev = get_event_pair(ctx);
+    PT_HIP(hipEventRecord(rev.first, ctx->stream));
   }
   for (uint32_t done = 0; done < num_samples;) {
     const uint32_t k = (uint32_t)std::min<uint64_t>(spb, num_samples - done);
@@ -965,6 +958,14 @@ int pt_trace_rays_device_noalloc(pt_ctx* ctx, const PtRay* device_rays, uint64_t
   if (num_rays >= (1ull << 31)) return ctx->fail(PT_ERR_INVALID_ARG, "pt_trace_rays_device_noalloc: at most 2^31 - 1 rays per call");
   // The spill region of the per-lane stacks comes out of the static scratch, so the persistent grid is cut to the
   // waves it has room for; a BVH so deep that not even one block per CU fits is rejected.
+  {   // the contract rests on k_extend_ns having no private segment: ask the runtime about the instantiation to be launched
+    size_t priv = 0;
+    const int qe = extend_ns_private_bytes(ctx->cfg.defer_entries > 0, ctx->ds.paired, &priv);
+    if (qe != 0) return ctx->fail(PT_ERR_HIP, "pt_trace_rays_device_noalloc: hipFuncGetAttributes failed");
+    if (priv != 0)
+      return ctx->fail(PT_ERR_UNSUPPORTED, "pt_trace_rays_device_noalloc: this build's k_extend_ns uses " + std::to_string(priv) +
+                                               " bytes of private segment per lane, which the runtime would allocate at launch");
+  }
   LaunchCfg cfg = ctx->cfg;
   // k_extend pins its register budget and spills a few registers to the private segment, which the runtime allocates
   // on demand; this entry point launches the instantiation that has none (one wave per SIMD less), on its own grid
@@ -1108,6 +1109,13 @@ int pt_debug_read_bvh(pt_ctx* ctx, void* nodes, uint64_t node_capacity, void* tr
 int pt_stats_get(pt_ctx* ctx, PtStats* out) {
   PT_REQUIRE_CTX();
   if (!out) return ctx->fail(PT_ERR_INVALID_ARG, "output pointer is null");
+  // PtStats is versioned by size (append-only): fill a local copy, hand back as many bytes as the caller's header has
+  const uint32_t caller_size = out->struct_size;
+  if (caller_size < 16u || caller_size > (1u << 16))
+    return ctx->fail(PT_ERR_INVALID_ARG, "PtStats.struct_size must be set to sizeof(PtStats) before pt_stats_get");
+  PtStats local;
+  PtStats* const caller_out = out;
+  out = &local;
   memset(out, 0, sizeof(*out));
   PT_HIP(hipStreamSynchronize(ctx->stream));
   collect_events(ctx);
@@ -1133,6 +1141,9 @@ int pt_stats_get(pt_ctx* ctx, PtStats* out) {
   for (int b = 0; b < 16; ++b) out->extend_launches_bounce[b] = ctx->extend_launches_bounce[b];
   out->extend_ms = ctx->extend_ms;
   out->render_ms = ctx->render_ms;
+  const uint32_t n = std::min<uint32_t>(caller_size, (uint32_t)sizeof(PtStats));
+  local.struct_size = n;
+  memcpy(caller_out, &local, n);
   return PT_OK;
 }
 

@@ -289,49 +289,8 @@ struct Traverser {
       n0 = make_uint4(a0.x, a0.y, a0.z, a0.w); n1 = make_uint4(a1.x, a1.y, a1.z, a1.w); n2 = make_uint4(a2.x, a2.y, a2.z, a2.w);
       n3 = make_uint4(a3.x, a3.y, a3.z, a3.w); n4 = make_uint4(a4.x, a4.y, a4.z, a4.w);
     } else {
-#ifdef PT_EXP_SPLIT_LOADS   // experiment: first 16 bytes alone (brings the line in), the other 64 once it has landed
-      n0 = np[0];
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      n1 = np[1]; n2 = np[2]; n3 = np[3]; n4 = np[4];
-#else
       n0 = np[0]; n1 = np[1]; n2 = np[2]; n3 = np[3]; n4 = np[4];
-#endif
     }
-#ifdef PT_EXP_EXTRA_VALU   // experiment: N more full-rate vector instructions per node step: what does a VALU instruction cost?
-    {
-      float d = __uint_as_float(ng.x);
-#pragma unroll
-      for (int k = 0; k < PT_EXP_EXTRA_VALU; ++k) asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(d));
-      asm volatile("" ::"v"(d));
-    }
-#endif
-#ifdef PT_EXP_EXTRA_SALU   // experiment: N more scalar ALU instructions (register adds) per node step: what does the scalar pipe cost?
-    {
-      uint32_t d = 1u;
-      asm volatile("s_mov_b32 %0, 1" : "=s"(d));
-#pragma unroll
-      for (int k = 0; k < PT_EXP_EXTRA_SALU; ++k) asm volatile("s_add_u32 %0, %0, %0" : "+s"(d) : : "scc");
-      asm volatile("" ::"s"(d));
-    }
-#endif
-#ifdef PT_EXP_EXTRA_LOADS   // experiment: the same 16-byte reads again (L1 hits, one landing register): what does an L1 access cost?
-    {
-      typedef unsigned int u4v __attribute__((ext_vector_type(4)));
-      u4v d;
-#if PT_EXP_EXTRA_LOADS == 5
-      asm volatile("global_load_dwordx4 %0, %1, off\n\tglobal_load_dwordx4 %0, %1, off offset:16\n\tglobal_load_dwordx4 %0, %1, off offset:32\n\t"
-                   "global_load_dwordx4 %0, %1, off offset:48\n\tglobal_load_dwordx4 %0, %1, off offset:64\n\ts_waitcnt vmcnt(0)"
-                   : "=&v"(d) : "v"((const void*)np) : "memory");
-#else
-      asm volatile("global_load_dwordx4 %0, %1, off\n\tglobal_load_dwordx4 %0, %1, off offset:16\n\tglobal_load_dwordx4 %0, %1, off offset:32\n\t"
-                   "global_load_dwordx4 %0, %1, off offset:48\n\tglobal_load_dwordx4 %0, %1, off offset:64\n\t"
-                   "global_load_dwordx4 %0, %1, off\n\tglobal_load_dwordx4 %0, %1, off offset:16\n\tglobal_load_dwordx4 %0, %1, off offset:32\n\t"
-                   "global_load_dwordx4 %0, %1, off offset:48\n\tglobal_load_dwordx4 %0, %1, off offset:64\n\ts_waitcnt vmcnt(0)"
-                   : "=&v"(d) : "v"((const void*)np) : "memory");
-#endif
-      asm volatile("" ::"v"(d));
-    }
-#endif
 
     const uint32_t e = n0.w;
 #if PT_MIX_FMA

@@ -40,6 +40,24 @@ class Camera:
         self.myPosition = eye.astype(np.float32)
         self.myOrientation = np.stack([r, u, f]).astype(np.float32)
 
+    def GetViewProj(self):
+        """Camera::myViewProj as PathTracer::CameraHasChanged reads it (PathTracer.cpp:446-453). FANCY's UpdateView /
+        UpdateProjection are absent; adopted definition: view = world -> (right, up, forward) camera axes, projection =
+        left-handed D3D perspective (vertical FOV, aspect, near, far), viewProj = proj * view, column vectors."""
+        R = self.myOrientation.astype(np.float64)
+        view = np.eye(4)
+        view[:3, :3] = R
+        view[:3, 3] = -R @ self.myPosition.astype(np.float64)
+        f = 1.0 / math.tan(math.radians(self.myFovDeg) * 0.5)
+        n, fr = float(self.myNear), float(self.myFar)
+        proj = np.zeros((4, 4))
+        proj[0, 0] = f / (self.myWidth / self.myHeight)
+        proj[1, 1] = f
+        proj[2, 2] = fr / (fr - n)
+        proj[2, 3] = -n * fr / (fr - n)
+        proj[3, 2] = 1.0
+        return (proj @ view).astype(np.float32)
+
     def GetVerticesOnNearPlane(self):
         """v0 bottom-left, v1 bottom-right, v2 top-right, v3 top-left of the near rectangle (vertical FOV)."""
         right, up, fwd = (self.myOrientation[i].astype(np.float32) for i in range(3))
@@ -94,8 +112,9 @@ class Sky:
 class PathTracer:
     """PathTracer — PathTracer/PathTracer.h:58-135, hot-path members only."""
 
-    def __init__(self, device=0, window_width=1280, window_height=720):
-        self.ctx = Context(device)
+    def __init__(self, device=0, window_width=1280, window_height=720, ctx=None):
+        # ctx: an existing context.Context (or, in the CPU tests of the accumulation control, a recorder with its methods)
+        self.ctx = ctx if ctx is not None else Context(device)
         self.myWindowWidth, self.myWindowHeight = int(window_width), int(window_height)
         # PathTracer.h:112-131
         self.myAoDistance = 1.0
@@ -121,11 +140,36 @@ class PathTracer:
         self._sky_dirty = True
         self.UpdateOutputTexture()
         self.InitSky()
+        self.myLastViewMat = self.myCamera.GetViewProj()       # PathTracer.h:115
+        self._last_sky = self._sky_settings()
 
     # ---- PathTracer.cpp:151-154 ----
     def InitSky(self):
         self.mySky = Sky(self.ctx)
         self._sky_dirty = True
+
+    # ---- PathTracer.cpp:446-453 ----
+    def CameraHasChanged(self):
+        """Any element of the view-projection matrix moved by more than 1e-4 since the last Update()."""
+        return bool(np.any(np.abs(self.myCamera.GetViewProj() - self.myLastViewMat) > np.float32(0.0001)))
+
+    def _sky_settings(self):
+        """What Sky_Imgui::HaveSettingsChanged watches (Sky_Imgui.cpp:10-43): sun direction / illuminance + atmosphere."""
+        import ctypes
+        return (bytes(np.asarray(self.mySky.mySunDir, dtype=np.float32)), bytes(np.asarray(self.mySky.mySunIlluminance, dtype=np.float32)),
+                ctypes.string_at(ctypes.addressof(self.mySky.myAtmosphereParams), ctypes.sizeof(self.mySky.myAtmosphereParams)))
+
+    # ---- PathTracer.cpp:557-571 (the per-frame accumulation control; no UI here) ----
+    def Update(self):
+        if not self.myAccumulate:
+            self.RestartAccumulation()          # always render frame 0 only (:562-564)
+        sky_now = self._sky_settings()
+        if sky_now != self._last_sky:           # mySky_Imgui.HaveSettingsChanged() (:566)
+            self._last_sky = sky_now
+            self.SkySettingsChanged()
+        if self.CameraHasChanged():             # (:566-568)
+            self.RestartAccumulation()
+        self.myLastViewMat = self.myCamera.GetViewProj()   # (:570)
 
     # ---- PathTracer.cpp:115-149 ----
     def LoadScene(self, scene, aCamPos=(0.0, 0.0, 0.0)):

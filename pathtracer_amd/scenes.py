@@ -398,6 +398,221 @@ def street(seed=2, target_tris=3145728):
 STREET_CAM = {"eye": (-100.0, 1.7, 0.5), "target": (60.0, 9.0, -1.0)}
 
 
+def _yaw_mesh(mesh, cx, cz, ang):
+    """Rotate a mesh about the vertical axis through (cx, cz): positions and normals (a rigid motion baked in)."""
+    v, idx = mesh
+    v = v.copy()
+    c, s = np.float64(np.cos(ang)), np.float64(np.sin(ang))
+    p = v["pos"].astype(np.float64)
+    x, z = p[:, 0] - cx, p[:, 2] - cz
+    v["pos"][:, 0] = (cx + c * x + s * z).astype(np.float32)
+    v["pos"][:, 2] = (cz - s * x + c * z).astype(np.float32)
+    n = v["normal"].astype(np.float64)
+    v["normal"][:, 0] = (c * n[:, 0] + s * n[:, 2]).astype(np.float32)
+    v["normal"][:, 2] = (-s * n[:, 0] + c * n[:, 2]).astype(np.float32)
+    return v, idx
+
+
+def _random_rotations(seed, tag, n):
+    """n uniformly distributed rotation matrices (n,3,3) from three hashed numbers each (Shoemake's quaternion method)."""
+    i = np.arange(n)
+    u1, u2, u3 = _rand01(seed, tag, i), _rand01(seed, tag + 1, i), _rand01(seed, tag + 2, i)
+    qx, qy = np.sqrt(1 - u1) * np.sin(2 * np.pi * u2), np.sqrt(1 - u1) * np.cos(2 * np.pi * u2)
+    qz, qw = np.sqrt(u1) * np.sin(2 * np.pi * u3), np.sqrt(u1) * np.cos(2 * np.pi * u3)
+    R = np.empty((n, 3, 3))
+    R[:, 0, 0] = 1 - 2 * (qy * qy + qz * qz); R[:, 0, 1] = 2 * (qx * qy - qz * qw); R[:, 0, 2] = 2 * (qx * qz + qy * qw)
+    R[:, 1, 0] = 2 * (qx * qy + qz * qw); R[:, 1, 1] = 1 - 2 * (qx * qx + qz * qz); R[:, 1, 2] = 2 * (qy * qz - qx * qw)
+    R[:, 2, 0] = 2 * (qx * qz - qy * qw); R[:, 2, 1] = 2 * (qy * qz + qx * qw); R[:, 2, 2] = 1 - 2 * (qx * qx + qy * qy)
+    return R
+
+
+def _boxes(centres, R, half):
+    """n oriented boxes (12 triangles, 24 vertices each) as one mesh: centres (n,3), rotations (n,3,3), half extents (n,3)."""
+    n = len(centres)
+    faces = []   # (normal axis, sign): 4 corners counter-clockwise seen from outside
+    for a in range(3):
+        b, c = (a + 1) % 3, (a + 2) % 3
+        for sgn in (-1.0, 1.0):
+            cs = []
+            for sb, sc in ((-1, -1), (1, -1), (1, 1), (-1, 1)) if sgn > 0 else ((-1, -1), (-1, 1), (1, 1), (1, -1)):
+                e = np.zeros(3); e[a] = sgn; e[b] = sb; e[c] = sc
+                cs.append(e)
+            nn = np.zeros(3); nn[a] = sgn
+            faces.append((np.array(cs), nn))
+    local = np.stack([f[0] for f in faces])               # (6,4,3) corner signs
+    fn = np.stack([f[1] for f in faces])                  # (6,3)
+    P = local[None] * half[:, None, None, :]              # (n,6,4,3)
+    P = np.einsum("nij,nfcj->nfci", R, P) + centres[:, None, None, :]
+    N = np.einsum("nij,fj->nfi", R, fn)                   # (n,6,3)
+    v = np.zeros(n * 24, dtype=api.VERTEX_DTYPE)
+    v["pos"] = P.reshape(-1, 3).astype(np.float32)
+    v["normal"] = np.repeat(N.reshape(-1, 3), 4, axis=0).astype(np.float32)
+    v["uv"] = np.tile(np.array([[0, 0], [1, 0], [1, 1], [0, 1]], dtype=np.float32), (n * 6, 1))
+    base = (4 * np.arange(n * 6)).astype(np.uint32)
+    idx = np.stack([base, base + 1, base + 2, base, base + 2, base + 3], axis=-1).reshape(-1).astype(np.uint32)
+    return v, idx
+
+
+def _rigid(R, t):
+    """Column-major 4x4 (glm::float4x4, PtInstanceDesc.myTransform) of x -> R x + t."""
+    m = np.eye(4)
+    m[:3, :3] = R
+    m[:3, 3] = t
+    return m.T.reshape(16).astype(np.float32)
+
+
+def street_hard(seed=4, target_tris=3145728):
+    """A SAH-hostile "Bistro-class" stand-in at exactly 3,145,728 triangles (review of round 2: the grid scenes flatter the
+    traversal). Nothing is axis-aligned: every building block is yawed by a random angle along a curved street and the
+    ground is yawed and tilted; 7.5 % of the triangles are long and thin (sagging cables of 6-sided tubes spanning
+    20-60 m, untessellated beams, banner quads tens of metres long, all running through finely tessellated detail);
+    clutter (bumpy shrubs, tessellated crates) is INSTANCED with uniformly random rotations in overlapping clusters
+    (real PtInstanceDesc transforms, flattened by pt_scene_create); the ground grid is 1 % of the budget and the
+    remainder is litter: small randomly oriented quads. 64 materials."""
+    meshes, instances = [], []
+    def add(mesh, mat, xf=None):
+        meshes.append(mesh)
+        instances.append((len(meshes) - 1, mat % 64, xf))
+    def centre_z(x):
+        return 6.0 * np.sin(np.asarray(x) / 40.0)
+    total = 0
+    # ---- 24 building blocks, each yawed: never within 8 degrees of an axis ----
+    k = 0
+    for side in (1.0, -1.0):
+        x = -118.0
+        for _ in range(12):
+            wdt = 14.0 + 8.0 * float(_rand01(seed, 10, k))
+            dpt = 16.0 + 4.0 * float(_rand01(seed, 12, k))
+            hgt = 10.0 + 18.0 * float(_rand01(seed, 11, k))
+            cx, cz = x + 0.5 * wdt, float(centre_z(x + 0.5 * wdt)) + side * 20.0
+            yaw = np.radians(8.0 + 74.0 * float(_rand01(seed, 13, k))) + 0.5 * np.pi * np.floor(4.0 * float(_rand01(seed, 14, k)))
+            m = _building_block(seed + 50 + k, cx - 0.5 * wdt, cx + 0.5 * wdt, cz - 0.5 * dpt, cz + 0.5 * dpt, hgt, 112, 96)
+            m = _yaw_mesh(m, cx, cz, yaw)
+            add(m, k)
+            total += len(m[1]) // 3
+            x += wdt + 1.5
+            k += 1
+    # ---- long thin geometry ----
+    # cables: 6-sided tubes of radius 1.5 cm, 10 segments along 20-60 m of sagging span across and along the street
+    n_cables = 1800
+    parts = []
+    for j in range(n_cables):
+        r = [float(_rand01(seed, 100 + q, j)) for q in range(8)]
+        xa = -115.0 + 230.0 * r[0]
+        xb = min(118.0, max(-118.0, xa + (20.0 + 40.0 * r[1]) * (1.0 if r[2] < 0.5 else -1.0)))
+        za, zb = float(centre_z(xa)) + (-14.0 + 28.0 * r[3]), float(centre_z(xb)) + (-14.0 + 28.0 * r[4])
+        ya, yb = 3.0 + 20.0 * r[5], 3.0 + 20.0 * r[6]
+        sag = 0.5 + 2.5 * r[7]
+        A, B = np.array([xa, ya, za]), np.array([xb, yb, zb])
+        axis = (B - A) / max(np.linalg.norm(B - A), 1e-9)
+        side_v = np.cross(axis, [0.0, 1.0, 0.0]); side_v /= max(np.linalg.norm(side_v), 1e-9)
+        up_v = np.cross(side_v, axis)
+        def fn(u, v, A=A, B=B, sag=sag, side_v=side_v, up_v=up_v):
+            c = A + (B - A) * u[..., None]
+            c[..., 1] -= sag * 4.0 * u * (1.0 - u)
+            ang = 2 * np.pi * v
+            return c + 0.015 * (np.cos(ang)[..., None] * side_v + np.sin(ang)[..., None] * up_v)
+        parts.append(_grid_mesh(fn, 10, 6))
+    cables = _merge(parts)
+    add(cables, 40)
+    total += len(cables[1]) // 3
+    # beams: 15 cm x 15 cm boxes 15-40 m long, random yaw, tilted up to 12 degrees, through the facades
+    n_beams = 1500
+    i = np.arange(n_beams)
+    bx = -118.0 + 236.0 * _rand01(seed, 120, i)
+    bc = np.stack([bx, 4.0 + 21.0 * _rand01(seed, 121, i), centre_z(bx) + (-24.0 + 48.0 * _rand01(seed, 122, i))], axis=-1)
+    yaw, tilt = 2 * np.pi * _rand01(seed, 123, i), np.radians(-12.0 + 24.0 * _rand01(seed, 124, i))
+    Rb = np.zeros((n_beams, 3, 3))
+    Rb[:, 0, 0] = np.cos(yaw) * np.cos(tilt); Rb[:, 0, 1] = -np.cos(yaw) * np.sin(tilt); Rb[:, 0, 2] = np.sin(yaw)
+    Rb[:, 1, 0] = np.sin(tilt); Rb[:, 1, 1] = np.cos(tilt)
+    Rb[:, 2, 0] = -np.sin(yaw) * np.cos(tilt); Rb[:, 2, 1] = np.sin(yaw) * np.sin(tilt); Rb[:, 2, 2] = np.cos(yaw)
+    beams = _boxes(bc, Rb, np.stack([7.5 + 12.5 * _rand01(seed, 125, i), np.full(n_beams, 0.075), np.full(n_beams, 0.075)], axis=-1))
+    add(beams, 41)
+    total += len(beams[1]) // 3
+    # banners / canopies: single quads 16-40 m x 2-5 m at random orientations above the street (two triangles spanning tens
+    # of metres each)
+    n_ban = 120
+    i = np.arange(n_ban)
+    Rq = _random_rotations(seed, 130, n_ban)
+    qx = -110.0 + 220.0 * _rand01(seed, 134, i)
+    qc = np.stack([qx, 9.0 + 16.0 * _rand01(seed, 135, i), centre_z(qx) + (-20.0 + 40.0 * _rand01(seed, 136, i))], axis=-1)
+    e1 = Rq[:, :, 0] * (8.0 + 12.0 * _rand01(seed, 137, i))[:, None]
+    e1[:, 1] *= 0.25                                                             # mostly level: they hang over the street, not into it
+    e2 = Rq[:, :, 1] * (1.0 + 1.5 * _rand01(seed, 138, i))[:, None]
+    v = np.zeros(4 * n_ban, dtype=api.VERTEX_DTYPE)
+    v["pos"] = np.stack([qc - e1 - e2, qc + e1 - e2, qc + e1 + e2, qc - e1 + e2], axis=1).reshape(-1, 3).astype(np.float32)
+    nq = np.cross(e1, e2)
+    v["normal"] = np.repeat(nq / np.maximum(np.linalg.norm(nq, axis=-1, keepdims=True), 1e-30), 4, axis=0).astype(np.float32)
+    v["uv"] = np.tile(np.array([[0, 0], [1, 0], [1, 1], [0, 1]], dtype=np.float32), (n_ban, 1))
+    base = (4 * i).astype(np.uint32)
+    add((v, np.stack([base, base + 1, base + 2, base, base + 2, base + 3], axis=-1).reshape(-1).astype(np.uint32)), 42)
+    total += 2 * n_ban
+    long_thin = total - 24 * (4 * 112 * 96 * 2 + 56 * 56 * 2)
+    # ---- instanced clutter with random rotations, in overlapping clusters ----
+    def shrub(u, v):
+        th, ph = 2 * np.pi * u, np.pi * (0.02 + 0.96 * v)
+        rr = 0.9 * (1.0 + 0.9 * _value_noise(seed + 300, u, v, 10.0) + 0.25 * np.cos(9 * th) * np.sin(7 * ph))
+        return np.stack([rr * np.sin(ph) * np.cos(th), rr * np.cos(ph), rr * np.sin(ph) * np.sin(th)], axis=-1)
+    shrub_mesh = _grid_mesh(shrub, 32, 32)                                                  # 2,048 triangles
+    parts = []
+    for a in range(3):                                                                      # crate: 6 faces of 8 x 8 quads = 768 triangles
+        for sgn in (-0.5, 0.5):
+            def fn(u, v, a=a, sgn=sgn):
+                p = [None, None, None]
+                p[a] = sgn + 0.02 * _value_noise(seed + 310 + a, u, v, 6.0)
+                p[(a + 1) % 3] = (u - 0.5) if sgn > 0 else (0.5 - u)
+                p[(a + 2) % 3] = v - 0.5
+                return np.stack(p, axis=-1)
+            parts.append(_grid_mesh(fn, 8, 8))
+    crate_mesh = _merge(parts)
+    meshes.append(shrub_mesh); shrub_id = len(meshes) - 1
+    meshes.append(crate_mesh); crate_id = len(meshes) - 1
+    n_shrub, n_crate, n_clusters = 220, 200, 60
+    cl = np.arange(n_clusters)
+    clx = -112.0 + 224.0 * _rand01(seed, 200, cl)
+    clz = centre_z(clx) + np.where(_rand01(seed, 201, cl) < 0.5, -1.0, 1.0) * (2.0 + 9.0 * _rand01(seed, 202, cl))
+    for kind, (mesh_id, count, ntri, scale0) in enumerate(((shrub_id, n_shrub, 2048, 1.0), (crate_id, n_crate, 768, 1.2))):
+        j = np.arange(count)
+        Rc = _random_rotations(seed, 210 + 10 * kind, count)
+        which = (_rand01(seed, 213 + 10 * kind, j) * n_clusters).astype(np.int64) % n_clusters
+        off = np.stack([-1.6 + 3.2 * _rand01(seed, 214 + 10 * kind, j), 0.3 + 1.8 * _rand01(seed, 215 + 10 * kind, j),
+                        -1.6 + 3.2 * _rand01(seed, 216 + 10 * kind, j)], axis=-1)
+        for q in range(count):
+            t = np.array([clx[which[q]], 0.0, clz[which[q]]]) + off[q]
+            instances.append((mesh_id, (44 + q) % 64, _rigid(Rc[q] * scale0, t)))
+        total += count * ntri
+    # ---- ground: 128 x 128 quads (1 % of the budget), yawed by 17 degrees and tilted, so its cells are not axis-aligned either ----
+    def ground(u, v):
+        x, z = -150.0 + 300.0 * u, -60.0 + 120.0 * v
+        c17, s17 = np.cos(np.radians(17.0)), np.sin(np.radians(17.0))
+        return np.stack([c17 * x + s17 * z, 0.004 * x - 0.006 * z + 0.03 * _value_noise(seed + 700, u, v, 96.0), -s17 * x + c17 * z], axis=-1)
+    g = _grid_mesh(ground, 128, 128)
+    add(g, 60)
+    total += len(g[1]) // 3
+    # ---- the remainder: litter, small randomly oriented quads near the ground along the street ----
+    rest = target_tris - total
+    assert rest > 0 and rest % 2 == 0, (total, rest)
+    n_lit = rest // 2
+    i = np.arange(n_lit)
+    Rl = _random_rotations(seed, 400, n_lit)
+    lx = -118.0 + 236.0 * _rand01(seed, 404, i)
+    lc = np.stack([lx, 0.05 + 2.5 * _rand01(seed, 405, i) ** 3, centre_z(lx) + (-12.0 + 24.0 * _rand01(seed, 406, i))], axis=-1)
+    e1, e2 = Rl[:, :, 0] * 0.12, Rl[:, :, 1] * 0.07
+    v = np.zeros(4 * n_lit, dtype=api.VERTEX_DTYPE)
+    v["pos"] = np.stack([lc - e1 - e2, lc + e1 - e2, lc + e1 + e2, lc - e1 + e2], axis=1).reshape(-1, 3).astype(np.float32)
+    v["normal"] = np.repeat(Rl[:, :, 2], 4, axis=0).astype(np.float32)
+    base = (4 * i).astype(np.uint32)
+    add((v, np.stack([base, base + 1, base + 2, base, base + 2, base + 3], axis=-1).reshape(-1).astype(np.uint32)), 61)
+    scene = SceneData(meshes, instances, _palette(seed, 64), name=f"street_hard(seed={seed})")
+    scene.long_thin_fraction = long_thin / float(target_tris)
+    assert scene.num_triangles == target_tris, scene.num_triangles
+    assert 0.05 <= scene.long_thin_fraction <= 0.10
+    return scene
+
+
+STREET_HARD_CAM = {"eye": (-95.0, 1.7, float(6.0 * np.sin(-95.0 / 40.0))), "target": (40.0, 8.0, float(6.0 * np.sin(1.0)))}
+
+
 def courtyard(seed=3, target_tris=10485760):
     """"San-Miguel-class" stand-in (config 5): an arcaded courtyard with many small leaf-like quads (high depth
     complexity). Exactly 10,485,760 triangles."""

@@ -252,14 +252,14 @@ def test_deep_hierarchy_with_every_stack_configuration(ctx, oracle):
     assert (ref["prim"] != api.PT_MISS).mean() > 0.5
     try:
         for lds, defer in ((8, 4), (128, 16), (1, 0), (2, 1), (64, 0)):
-            ctx.set_option(api.PT_OPT_EXTEND_LDS_STACK, lds)
-            ctx.set_option(api.PT_OPT_EXTEND_DEFER, defer)
+            ctx.set_tuning(api.PT_TUNE_EXTEND_LDS_STACK, lds)
+            ctx.set_tuning(api.PT_TUNE_EXTEND_DEFER, defer)
             got = ctx.trace_rays(rays)
             assert np.array_equal(got["prim"], ref["prim"]), (lds, defer)
             assert np.array_equal(got["t"].view(np.uint32), ref["t"].view(np.uint32)), (lds, defer)
     finally:
-        ctx.set_option(api.PT_OPT_EXTEND_LDS_STACK, 6)
-        ctx.set_option(api.PT_OPT_EXTEND_DEFER, 4)
+        ctx.set_tuning(api.PT_TUNE_EXTEND_LDS_STACK, 6)
+        ctx.set_tuning(api.PT_TUNE_EXTEND_DEFER, 4)
 
 
 def test_coincident_geometry_resolves_ties_to_the_lower_triangle_id(ctx, oracle):
@@ -496,6 +496,62 @@ def test_street_3m_triangles_hits_and_image_match_oracle(ctx, oracle):
     assert rel_mse(img, acc / 2.0) < 1e-4, rel_mse(img, acc / 2.0)
 
 
+def test_street_hard_sah_hostile_scene_hits_and_image_match_oracle(ctx, oracle):
+    """The SAH-hostile C4 stand-in (scenes.street_hard: every block yawed, 7.4 % long thin triangles — cables, beams,
+    banners — running through finely tessellated detail, instanced clutter with random rotations, litter quads) at its
+    full 3,145,728 triangles. The builder answers it with spatial splits, so a triangle is referenced from several
+    leaves; hit records must not notice: 200 k incoherent rays bit-identical to the oracle's own (object-split) BVH, and
+    a depth-8 image within the north-star tolerance."""
+    sc = scenes.street_hard(4)
+    assert 0.05 <= sc.long_thin_fraction <= 0.10
+    ctx.scene_create(sc)
+    osc = oracle.scene(sc)
+    info = ctx.scene_info()
+    assert info.num_triangles == 3145728
+    nodes, recs, _ = ctx.debug_read_bvh()
+    assert len(recs) > 1.2 * info.num_triangles          # the spatial splits really happened (references > triangles)
+    rays = random_rays(43, 200000, list(info.bounds_min), list(info.bounds_max), tmin=0.001, tmax=10000.0)
+    got, ref = ctx.trace_rays(rays), osc.trace_rays(rays)
+    assert np.array_equal(got["prim"], ref["prim"])
+    hit = ref["prim"] != api.PT_MISS
+    assert 0.2 < hit.mean() < 1.0
+    for f in ("t", "u", "v"):
+        assert np.array_equal(got[f][hit].view(np.uint32), ref[f][hit].view(np.uint32)), f
+    atm = oracle.earth_atmosphere()
+    ctx.sky_set(atm)
+    olut = oracle.transmittance_lut(atm)
+    w, h = 160, 90
+    c = lookat_consts(w, h, scenes.STREET_HARD_CAM, depth=8)
+    ctx.accum_reset(w, h)
+    ctx.stats_reset()
+    ctx.render(c, w, h, 0, 2)
+    img = ctx.accum_read()
+    st = ctx.stats()
+    acc, ost, _ = osc.render(c, w, h, 0, 2, lut=olut)
+    print("street_hard rays", st.rays, ost["rays"], "sky", st.sky_misses, ost["sky_misses"], "relMSE", rel_mse(img, acc / 2.0))
+    assert abs(st.rays - ost["rays"]) <= 3e-4 * ost["rays"]
+    assert rel_mse(img, acc / 2.0) < 1e-4, rel_mse(img, acc / 2.0)
+
+
+def test_stats_struct_is_versioned_by_size(ctx):
+    """PtStats.struct_size: a caller built against an OLDER (shorter) header gets exactly the bytes it knows, a caller that
+    forgot to set the size is refused."""
+    import ctypes as C
+    lib = ctx.lib
+    full = api.PtStats()
+    full.struct_size = C.sizeof(api.PtStats)
+    assert lib.pt_stats_get(ctx.h, C.byref(full)) == api.PT_OK and full.struct_size == C.sizeof(api.PtStats)
+    buf = (C.c_ubyte * C.sizeof(api.PtStats))(*([0xAB] * C.sizeof(api.PtStats)))
+    short = api.PtStats.from_buffer(buf)
+    short.struct_size = 72                                   # an older header that ended after extend_launches
+    assert lib.pt_stats_get(ctx.h, C.byref(short)) == api.PT_OK and short.struct_size == 72
+    assert bytes(buf[72:]) == b"\xab" * (C.sizeof(api.PtStats) - 72)      # nothing written past the caller's size
+    assert short.rays == full.rays
+    zero = api.PtStats()
+    assert lib.pt_stats_get(ctx.h, C.byref(zero)) == api.PT_ERR_INVALID_ARG
+    assert ctx.lib.pt_set_option(ctx.h, api.PT_TUNE_EXTEND_DEFER, 4) == api.PT_ERR_INVALID_ARG   # tuning ids are not options
+
+
 # ---------------------------------------------------------------------------------------------- BASELINE C4 / C5 as stated
 def test_street_c4_with_ggx_material_extension_matches_oracle(ctx, oracle):
     """BASELINE config C4 as it is worded ("~3M tris, 8 bounces, textured GGX materials"): street(2) with the material
@@ -583,24 +639,24 @@ def test_count_kernel_matches_host_walker_on_the_same_bvh8(ctx, oracle, pairs):
     assert len(nodes) == info.num_bvh_nodes and tris.shape[1] == (64 if pairs else 48)
     if pairs:
         assert info.num_triangles // 2 <= len(tris) < 0.6 * info.num_triangles   # made of quads: nearly every triangle finds its pair
-    else:
-        assert len(tris) == info.num_triangles
+    else:   # spatial splits may reference a triangle from several leaves
+        assert info.num_triangles <= len(tris) <= 2 * info.num_triangles
     rays = random_rays(77, 100000, list(info.bounds_min), list(info.bounds_max), tmin=0.001, tmax=10000.0)
     whits = np.empty(len(rays), dtype=api.HIT_DTYPE)
     cn, ct = C.c_uint64(), C.c_uint64()
     assert wl.bvh8_walk(api.ptr(nodes), len(nodes), api.ptr(tris), len(tris), tris.shape[1], mag, api.ptr(rays), len(rays), api.ptr(whits),
                         C.byref(cn), C.byref(ct)) == 0
     try:
-        ctx.set_option(api.PT_OPT_EXTEND_DEFER, 0)
-        ctx.set_option(api.PT_OPT_EXTEND_POSTPONE_PCT, 0)        # canonical schedule: what bench.py's count_pass(0, 0) runs
+        ctx.set_tuning(api.PT_TUNE_EXTEND_DEFER, 0)
+        ctx.set_tuning(api.PT_TUNE_EXTEND_POSTPONE_PCT, 0)        # canonical schedule: what bench.py's count_pass(0, 0) runs
         ctx.set_option(api.PT_OPT_COUNT_TRAVERSAL, 1)
         ctx.stats_reset()
         got = ctx.trace_rays(rays)
         st = ctx.stats()
     finally:
         ctx.set_option(api.PT_OPT_COUNT_TRAVERSAL, 0)
-        ctx.set_option(api.PT_OPT_EXTEND_DEFER, 4)
-        ctx.set_option(api.PT_OPT_EXTEND_POSTPONE_PCT, 40)
+        ctx.set_tuning(api.PT_TUNE_EXTEND_DEFER, 4)
+        ctx.set_tuning(api.PT_TUNE_EXTEND_POSTPONE_PCT, 40)
     assert np.array_equal(got.view(np.uint32), whits.view(np.uint32))
     assert (st.nodes_visited, st.tris_tested) == (cn.value, ct.value)
     assert 5 < cn.value / len(rays) < 60 and 1 < ct.value / len(rays) < 40
@@ -685,8 +741,22 @@ def test_bench_gpus_2_starts_two_ranks_by_itself():
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout
     out = json.loads(lines[0])
-    assert out["n_gpus"] == 2 and out["value"] > 0 and out["scaling"] == "weak"
-    assert out["config"]["parallelism"] == "sample-partition x2"
+    # N > 1 is strong scaling by default (BASELINE C3: a fixed sample count split over the GPUs): 1 step x 2 spp = 2 spp over 2 ranks
+    assert out["n_gpus"] == 2 and out["value"] > 0 and out["scaling"] == "strong"
+    assert out["config"]["job_spp"] == 2 and out["config"]["spp_this_rank"] == 1 and out["samples_reduced"] == 2
+    assert len(out["per_rank_ms"]) == 2 and out["config"]["parallelism"].startswith("sample-partition x2")
+    weak = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--weak"] + args, capture_output=True, text=True, timeout=170, env=env)
+    assert weak.returncode == 0, weak.stderr[-2000:]
+    wout = json.loads([ln for ln in weak.stdout.splitlines() if ln.startswith("{")][0])
+    assert wout["scaling"] == "weak" and wout["config"]["job_spp"] == 4 and wout["samples_reduced"] == 4
+    # --bit-identical: the 8 fixed virtual partitions give the same image bits for 1 and 2 ranks
+    shas = []
+    for n in (1, 2):
+        r2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(n), "--bit-identical", "--total-spp", "16"] + args,
+                            capture_output=True, text=True, timeout=170, env=env)
+        assert r2.returncode == 0, r2.stderr[-2000:]
+        shas.append(json.loads([ln for ln in r2.stdout.splitlines() if ln.startswith("{")][0])["image_sha256"])
+    assert shas[0] and shas[0] == shas[1]
     env["WORLD_SIZE"] = "1"
     bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"] + args, capture_output=True, text=True, timeout=170, env=env)
     assert bad.returncode == 2 and "WORLD_SIZE" in bad.stderr
@@ -694,14 +764,15 @@ def test_bench_gpus_2_starts_two_ranks_by_itself():
 
 # ---------------------------------------------------------------------------------------------- schedule options
 @pytest.mark.parametrize("fetch_min,postpone,blocks,lds_stack,defer", [
-    (16, 50, 0, 8, 4),      # shipped defaults
+    (16, 40, 0, 6, 4),      # the shipped defaults (csrc/kernels.h LaunchCfg), set explicitly
+    (16, 50, 0, 8, 4),      # round-1 schedule: 50 % postpone threshold, 8-entry LDS stack
     (1, 0, 1, 1, 0),        # stack postponing off, one LDS stack entry: everything deeper goes through the global spill
     (64, 100, 2, 2, 1),     # refill only when the whole wave is idle, always postpone, one parked group
     (32, 25, 3, 3, 16),     # large deferred queue
     (8, 75, 0, 128, 0),     # whole stack in LDS (more than 64 KB of dynamic LDS), stack postponing
 ])
 def test_extend_schedule_options_never_change_hits(ctx, oracle, fetch_min, postpone, blocks, lds_stack, defer):
-    """The PT_OPT_EXTEND_* values only reorder work inside the traversal kernel: closest hits stay bit-identical to
+    """The PT_TUNE_EXTEND_* knobs (include/pt_api_tuning.h) only reorder work inside the traversal kernel: closest hits stay bit-identical to
     the oracle and occlusion answers stay equal, including through the global stack-spill path."""
     sc = scenes.atrium(1)
     ctx.scene_create(sc)
@@ -709,17 +780,17 @@ def test_extend_schedule_options_never_change_hits(ctx, oracle, fetch_min, postp
     info = ctx.scene_info()
     rays = random_rays(31, 150000, list(info.bounds_min), list(info.bounds_max), tmin=0.001, tmax=10000.0)
     ref = osc.trace_rays(rays)
-    opts = ((api.PT_OPT_EXTEND_FETCH_MIN, fetch_min, 16), (api.PT_OPT_EXTEND_POSTPONE_PCT, postpone, 40),
-            (api.PT_OPT_EXTEND_BLOCKS_PER_CU, blocks, 0), (api.PT_OPT_EXTEND_LDS_STACK, lds_stack, 6),
-            (api.PT_OPT_EXTEND_DEFER, defer, 4))
+    opts = ((api.PT_TUNE_EXTEND_FETCH_MIN, fetch_min, 16), (api.PT_TUNE_EXTEND_POSTPONE_PCT, postpone, 40),
+            (api.PT_TUNE_EXTEND_BLOCKS_PER_CU, blocks, 0), (api.PT_TUNE_EXTEND_LDS_STACK, lds_stack, 6),
+            (api.PT_TUNE_EXTEND_DEFER, defer, 4))
     try:
         for o, v, _ in opts:
-            ctx.set_option(o, v)
+            ctx.set_tuning(o, v)
         got = ctx.trace_rays(rays)
         occ = ctx.occluded(rays)
     finally:
         for o, _, d in opts:
-            ctx.set_option(o, d)
+            ctx.set_tuning(o, d)
     assert np.array_equal(got["prim"], ref["prim"])
     hit = ref["prim"] != api.PT_MISS
     for f in ("t", "u", "v"):

@@ -19,9 +19,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_library_loads_and_exports_every_declared_symbol():
     lib = api.load_library()
-    header = open(os.path.join(ROOT, "include", "pt_api.h")).read()
+    header = open(os.path.join(ROOT, "include", "pt_api.h")).read() + open(os.path.join(ROOT, "include", "pt_api_tuning.h")).read()
     declared = set(re.findall(r"^(?:int|const char\*)\s+(pt_[a-z_]+)\s*\(", header, flags=re.M))
-    assert declared, "no declarations parsed from pt_api.h"
+    assert declared and "pt_debug_set_tuning" in declared, "no declarations parsed from include/*.h"
     assert declared == set(api.SYMBOLS), declared ^ set(api.SYMBOLS)
     for name in declared:
         assert getattr(lib, name) is not None
@@ -48,14 +48,14 @@ def test_ctypes_mirrors_have_the_c_header_struct_sizes(tmp_path):
     pointer: a C program compiled against the header prints sizeof / offsetof, ctypes must report the same."""
     import subprocess
     src = tmp_path / "sizes.c"
-    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "pt_api.h"\nint main(void) {\n'
-                   '  printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(PtStats), offsetof(PtStats, extend_launches_bounce), '
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "pt_api_tuning.h"\nint main(void) {\n'
+                   '  printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n", offsetof(PtStats, struct_size), offsetof(PtStats, samples), sizeof(PtStats), offsetof(PtStats, extend_launches_bounce), '
                    'offsetof(PtStats, packet_launches), offsetof(PtStats, packet_cal_ms), sizeof(PtSceneInfo), sizeof(PtAtmosphere), sizeof(PtInstanceDesc), '
                    'sizeof(PtRtConsts), sizeof(PtMaterialExt), sizeof(PtMeshDesc));\n  return 0;\n}\n')
     exe = tmp_path / "sizes"
-    subprocess.check_call(["gcc", "-std=c11", "-I", os.path.join(ROOT, "include"), "-o", str(exe), str(src)])
+    subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"), "-o", str(exe), str(src)])
     got = [int(x) for x in subprocess.check_output([str(exe)]).split()]
-    want = [C.sizeof(api.PtStats), api.PtStats.extend_launches_bounce.offset, api.PtStats.packet_launches.offset, api.PtStats.packet_cal_ms.offset,
+    want = [0, 8, C.sizeof(api.PtStats), api.PtStats.extend_launches_bounce.offset, api.PtStats.packet_launches.offset, api.PtStats.packet_cal_ms.offset,
             C.sizeof(api.PtSceneInfo), C.sizeof(api.PtAtmosphere), C.sizeof(api.PtInstanceDesc), C.sizeof(api.PtRtConsts), C.sizeof(api.PtMaterialExt),
             C.sizeof(api.PtMeshDesc)]
     assert got == want
@@ -299,6 +299,66 @@ def test_image_io_roundtrip_and_png_signature(tmp_path):
     assert len(raw) == h * (1 + 3 * w)
 
 
+# ---------------------------------------------------------------------------------------------- accumulation control
+class _RecorderCtx:
+    """Stands in for context.Context: records the C-ABI calls the host mirror would make (no GPU needed)."""
+    def __init__(self):
+        self.calls = []
+    def accum_reset(self, w, h): self.calls.append(("accum_reset", w, h))
+    def sky_set(self, atm): self.calls.append(("sky_set",))
+    def scene_create(self, scene, flags=0): self.calls.append(("scene_create",))
+    def render(self, consts, w, h, first, n): self.calls.append(("render", w, h, first, n))
+    def render_ao(self, consts, w, h, first, n): self.calls.append(("render_ao", w, h, first, n))
+
+
+def test_update_restarts_accumulation_like_the_reference():
+    """PathTracer::Update (PathTracer.cpp:557-571) + CameraHasChanged (:446-453, epsilon 1e-4 on the view-projection
+    matrix) + the sky-settings check (:566): accumulation restarts exactly when the reference's would, and the frame
+    counter / clear flag drive pt_accum_reset and the first_sample argument of pt_render as RenderRT (:668-678,763-764) does."""
+    from pathtracer_amd.pathtracer import PathTracer
+    rec = _RecorderCtx()
+    pt = PathTracer(0, 1280, 720, ctx=rec)
+    pt.LoadScene(scenes.cornell_box(), scenes.CORNELL_CAM_POS)
+    def frame(n=1):
+        pt.Update()
+        pt.RenderRT(n)
+    rec.calls.clear()
+    frame(); frame(); frame(2)
+    renders = [c for c in rec.calls if c[0] == "render"]
+    assert [c[3:] for c in renders] == [(0, 1), (1, 1), (2, 2)]            # frames accumulate: first_sample = frames so far
+    assert sum(c[0] == "accum_reset" for c in rec.calls) == 1              # LoadScene asked for one clear (camera moved too)
+    assert pt.myNumAccumulationFrames == 4 and not pt.CameraHasChanged()
+    # a move below the epsilon keeps accumulating; above it restarts
+    rec.calls.clear()
+    pt.myCamera.myPosition = pt.myCamera.myPosition + np.float32(1e-6)
+    assert not pt.CameraHasChanged()
+    frame()
+    assert [c for c in rec.calls if c[0] == "accum_reset"] == [] and rec.calls[-1][3:] == (4, 1)
+    pt.myCamera.myPosition = pt.myCamera.myPosition + np.array([0.5, 0.0, 0.0], dtype=np.float32)
+    assert pt.CameraHasChanged()
+    frame()
+    assert rec.calls[-2][0] == "accum_reset" and rec.calls[-1][3:] == (0, 1) and pt.myNumAccumulationFrames == 1
+    assert not pt.CameraHasChanged()                                        # myLastViewMat was refreshed by Update (:570)
+    # rotating the camera counts as well
+    pt.myCamera.LookAt(pt.myCamera.myPosition, pt.myCamera.myPosition + np.array([0.3, 0.0, 1.0], dtype=np.float32))
+    frame()
+    assert rec.calls[-2][0] == "accum_reset" and rec.calls[-1][3:] == (0, 1)
+    # sky settings: a new sun direction recomputes the LUT and restarts (Sky_Imgui::HaveSettingsChanged)
+    rec.calls.clear()
+    pt.mySky.mySunDir = np.array([0.0, 0.6, 0.8], dtype=np.float32)
+    frame()
+    assert [c[0] for c in rec.calls] == ["accum_reset", "sky_set", "render"] and rec.calls[-1][3:] == (0, 1)
+    # myAccumulate = false: always frame 0 (:562-564)
+    pt.myAccumulate = False
+    rec.calls.clear()
+    frame(); frame()
+    assert [c[3:] for c in rec.calls if c[0] == "render"] == [(0, 1), (0, 1)] and sum(c[0] == "accum_reset" for c in rec.calls) == 2
+    # the AO toggle selects the other pipeline for the same dispatch (:680-683)
+    pt.myRenderAo = True
+    frame()
+    assert rec.calls[-1][0] == "render_ao"
+
+
 # ---------------------------------------------------------------------------------------------- BVH8 builder on the CPU
 def _flat_triangles(sc):
     """Triangle list in primitive order for scenes whose instances carry no transform (InitRtScene order: instance by
@@ -346,8 +406,9 @@ def test_bvh8_builder_both_leaf_formats_walk_to_the_oracle_hits(oracle, scene):
                                       api.ptr(info)) == 0
         assert np.array_equal(hits.view(np.uint32), want.view(np.uint32)), mode
         stats[mode] = (int(info[0]), int(info[1]), int(info[2]), int(info[3]), int(cn[0]), int(ct[0]))
-    assert stats[0][1:4] == (len(tris), 0, 48) and stats[1][3] == 64
-    assert stats[1][1] + stats[1][2] == len(tris)                 # every triangle is in exactly one record
+    # spatial splits (SBVH) may reference a triangle from more than one leaf: records >= triangles, within the split budget
+    assert len(tris) <= stats[0][1] <= 1.3 * len(tris) + 1 and stats[0][2:4] == (0, 48) and stats[1][3] == 64
+    assert len(tris) <= stats[1][1] + stats[1][2] <= 1.3 * len(tris) + 1     # every triangle is in at least one record
     if scene == "atrium":
         assert stats[1][2] > 0.45 * len(tris) and stats[1][0] < 0.8 * stats[0][0]     # quads pair up; fewer nodes
     else:

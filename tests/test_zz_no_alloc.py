@@ -38,6 +38,21 @@ def test_noalloc_trace_matches_allocating_entry_point(ctx):
     small = random_rays(72, 777, list(info.bounds_min), list(info.bounds_max), tmin=0.001, tmax=10000.0)
     a, b = both(small)                                  # second call in a row, smaller input
     assert np.array_equal(a, b)
+    # "allocates nothing" measured, not assumed: after the warm calls above, the driver's free-memory figure must not move
+    # across further noalloc calls (a private segment, had the kernel one, would be allocated by the runtime at launch;
+    # the entry point also refuses to run then: extend_ns_private_bytes in kernels.hip)
+    n = len(big)
+    d_rays = torch.from_numpy(big.view(np.float32).reshape(n, 8).copy()).to(dev)
+    d_hits = torch.empty((n, 4), dtype=torch.float32, device=dev)
+    torch.cuda.synchronize()
+    ctx.trace_rays_device_noalloc(d_rays.data_ptr(), n, d_hits.data_ptr())
+    ctx.synchronize()
+    free0 = torch.cuda.mem_get_info(dev)[0]
+    for _ in range(2):
+        ctx.trace_rays_device_noalloc(d_rays.data_ptr(), n, d_hits.data_ptr())
+        ctx.synchronize()
+        assert torch.cuda.mem_get_info(dev)[0] == free0
+    del d_rays, d_hits
     # a deep hierarchy exercises the spill region that lives in the static scratch
     from tests.test_gpu_parity import deep_hierarchy_scene
     deep, rays = deep_hierarchy_scene()

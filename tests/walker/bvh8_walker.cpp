@@ -179,3 +179,34 @@ extern "C" int bvh8_build_and_walk(const float* verts, uint32_t num_tris, int pa
   return bvh8_walk(b.nodes.data(), b.nodes.size(), b.records(), b.num_records(), (uint32_t)b.record_bytes(), mag, rays, n, hits,
                    nodes_opened, tris_tested);
 }
+
+// Build once, walk many ray sets (tools/bvh_cpu_quality.py: builder experiments without a GPU). The walk is split over
+// `threads` host threads by ray ranges; the counters are summed.
+#include <thread>
+extern "C" void* bvh8_build(const float* verts, uint32_t num_tris, int pair_mode, int threads, uint64_t* info) {
+  pt::Bvh8* b = new pt::Bvh8();
+  pt::build_bvh8(verts, num_tris, *b, threads, pair_mode);
+  info[0] = b->nodes.size(); info[1] = b->num_records(); info[2] = b->num_pairs; info[3] = b->record_bytes(); info[4] = b->max_depth;
+  info[5] = (uint64_t)b->build_ms;
+  return b;
+}
+extern "C" void bvh8_free(void* h) { delete static_cast<pt::Bvh8*>(h); }
+extern "C" int bvh8_walk_built(void* h, const Ray* rays, uint64_t n, Hit* hits, uint64_t* nodes_opened, uint64_t* tris_tested, int threads) {
+  const pt::Bvh8& b = *static_cast<pt::Bvh8*>(h);
+  float mag = 0.0f;
+  for (int a = 0; a < 3; ++a) mag = std::fmax(mag, std::fmax(std::fabs(b.lo[a]), std::fabs(b.hi[a])));
+  if (threads < 1) threads = 1;
+  std::vector<uint64_t> cn(threads, 0), ct(threads, 0);
+  std::vector<int> rc(threads, 0);
+  std::vector<std::thread> pool;
+  for (int t = 0; t < threads; ++t) {
+    const uint64_t a = n * (uint64_t)t / threads, e = n * (uint64_t)(t + 1) / threads;
+    pool.emplace_back([&, t, a, e] {
+      rc[t] = bvh8_walk(b.nodes.data(), b.nodes.size(), b.records(), b.num_records(), (uint32_t)b.record_bytes(), mag, rays + a, e - a, hits + a, &cn[t], &ct[t]);
+    });
+  }
+  for (auto& th : pool) th.join();
+  *nodes_opened = 0; *tris_tested = 0;
+  for (int t = 0; t < threads; ++t) { if (rc[t]) return rc[t]; *nodes_opened += cn[t]; *tris_tested += ct[t]; }
+  return 0;
+}

@@ -21,7 +21,7 @@ ctx.accum_reset(w, h)
 ctx.render(c, w, h, 0, 1)
 ctx.synchronize()
 rays = ctx.debug_read_queue(depth)          # the last bounce's (incoherent) rays
-ctx.set_option(api.PT_OPT_EXTEND_DEFER, 0); ctx.set_option(api.PT_OPT_EXTEND_POSTPONE_PCT, 0); ctx.set_option(api.PT_OPT_COUNT_TRAVERSAL, 1)
+ctx.set_tuning(api.PT_TUNE_EXTEND_DEFER, 0); ctx.set_tuning(api.PT_TUNE_EXTEND_POSTPONE_PCT, 0); ctx.set_option(api.PT_OPT_COUNT_TRAVERSAL, 1)
 ctx.stats_reset()
 got = ctx.trace_rays(rays)
 st = ctx.stats()

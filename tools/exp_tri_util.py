@@ -18,7 +18,7 @@ ctx.set_option(api.PT_OPT_SAMPLES_PER_BATCH, SPP)
 grid = [(50, 25, 4), (50, 50, 4), (75, 50, 4), (75, 75, 4), (90, 75, 4), (50, 25, 6), (75, 75, 6), (90, 90, 6), (25, 10, 4), (0, 0, 4)]
 rows = []
 for (post, cont, defer) in grid:
-    ctx.set_option(api.PT_OPT_EXTEND_POSTPONE_PCT, post); ctx.set_option(api.PT_OPT_EXTEND_CONTINUE_PCT, cont); ctx.set_option(api.PT_OPT_EXTEND_DEFER, defer)
+    ctx.set_tuning(api.PT_TUNE_EXTEND_POSTPONE_PCT, post); ctx.set_tuning(api.PT_TUNE_EXTEND_CONTINUE_PCT, cont); ctx.set_tuning(api.PT_TUNE_EXTEND_DEFER, defer)
     ctx.set_option(api.PT_OPT_COUNT_TRAVERSAL, 1); ctx.stats_reset()
     ctx.render(c, W, H, 0, SPP)
     s = ctx.stats()

@@ -26,7 +26,7 @@ def make(spp):
 
 def run(pts, spp_each, blocks_per_cu=0):
     for p in pts:
-        p.ctx.set_option(api.PT_OPT_EXTEND_BLOCKS_PER_CU, blocks_per_cu)
+        p.ctx.set_tuning(api.PT_TUNE_EXTEND_BLOCKS_PER_CU, blocks_per_cu)
     cs = [p.BuildRtConsts() for p in pts]
     def step(i):
         for k, p in enumerate(pts):

@@ -9,7 +9,7 @@ pt.mySky.ComputeTranmittanceLut(); pt._sky_dirty = False
 c = pt.BuildRtConsts(); ctx = pt.ctx
 ctx.set_option(api.PT_OPT_SAMPLES_PER_BATCH, SPP); ctx.set_option(api.PT_OPT_TIME_KERNELS, 1)
 for dq in (4, 0):
-    ctx.set_option(api.PT_OPT_EXTEND_DEFER, dq)
+    ctx.set_tuning(api.PT_TUNE_EXTEND_DEFER, dq)
     for i in range(24):
         ctx.stats_reset(); ctx.render(c, W, H, i * SPP, SPP); s = ctx.stats()
         print(dq, i, " ".join(f"{s.extend_ms_bounce[b]:7.3f}" for b in range(5)), f"render {s.render_ms:7.3f}", flush=True)

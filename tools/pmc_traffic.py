@@ -1,10 +1,14 @@
-"""Turns the FETCH_SIZE / WRITE_SIZE passes of tools/prof_pmc.sh into one entry of profiles/r02/pmc_traffic.json.
+"""Turns the FETCH_SIZE / WRITE_SIZE passes of tools/prof_pmc.sh into one entry of profiles/<PT_PROFILE_ROUND, default r03>/pmc_traffic.json.
+Every entry carries build_fingerprint = bench.build_fingerprint() of the tree the passes ran on (sha256 of the kernel sources):
+bench.py pairs an entry's counters with its live launch times only when the fingerprints agree, and prints pmc_stale otherwise.
 usage: python tools/pmc_traffic.py <tag> <workload> <width> <height> <spp_per_step> <depth>
 Units and corrections follow MI355X_MICROARCH.md (HBM section): FETCH_SIZE/WRITE_SIZE are KB of L2<->fabric requests
 (Infinity-Cache hits included); on gfx950 FETCH_SIZE tallies a 128-byte request as 64 bytes for 16-byte-per-lane reads,
 so it is doubled; the node/triangle gathers of k_extend are 16 bytes per lane but not streaming, i.e. outside the
 calibrated pattern - the figure is an estimate and is labelled so."""
 import csv, glob, json, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench   # noqa: E402  (build_fingerprint)
 from collections import defaultdict
 
 tag, workload, w, h, spp, depth = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]), int(sys.argv[6])
@@ -14,7 +18,7 @@ for f in glob.glob(f"gpurun_out/pmc_{tag}/pass*/**/*counter_collection.csv", rec
         k = r["Kernel_Name"].split("(")[0].replace("void ", "").split("<")[0]
         acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
         calls[k][r["Counter_Name"]] += 1
-out = {"workload": workload, "width": w, "height": h, "spp_per_step": spp, "depth": depth, "kernels": {}}
+out = {"workload": workload, "width": w, "height": h, "spp_per_step": spp, "depth": depth, "build_fingerprint": bench.build_fingerprint(), "kernels": {}}
 for k in acc:
     if "FETCH_SIZE" not in acc[k]:
         continue
@@ -47,7 +51,8 @@ for extra in sys.argv[7:]:          # optional key=value pairs: material_ext=1 r
 out["note"] = ("rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE (separate passes), mean over the k_extend launches of bench.py --steps 2; "
                "bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024, the gfx950 doubling of FETCH_SIZE applied although the BVH gathers are "
                "not the calibrated streaming pattern; fabric-side, Infinity-Cache hits included")
-path = "profiles/r02/pmc_traffic.json"
+path = "profiles/%s/pmc_traffic.json" % os.environ.get("PT_PROFILE_ROUND", "r03")
+os.makedirs(os.path.dirname(path), exist_ok=True)
 cur = json.load(open(path)) if os.path.exists(path) else []
 key = lambda c: (c["workload"], c["width"], c["height"], c["spp_per_step"], c["depth"], c.get("material_ext", 0), c.get("russian_roulette", 0))
 cur = [c for c in cur if key(c) != key(out)] + [out]

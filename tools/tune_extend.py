@@ -23,12 +23,12 @@ else:
 res = {g: [] for g in grid}
 for rnd in range(3):
     for g in grid:
-        ctx.set_option(api.PT_OPT_EXTEND_FETCH_MIN, g[0]); ctx.set_option(api.PT_OPT_EXTEND_POSTPONE_PCT, g[1])
-        ctx.set_option(api.PT_OPT_EXTEND_LDS_STACK, g[3] if g[3] else 6)
-        ctx.set_option(api.PT_OPT_EXTEND_BLOCKS_PER_CU, g[2])
-        ctx.set_option(api.PT_OPT_EXTEND_DEFER, g[4] if g[4] else 4)
-        ctx.set_option(api.PT_OPT_EXTEND_TOP_NODES, g[5] if len(g) > 5 else 73)
-        ctx.set_option(api.PT_OPT_EXTEND_CONTINUE_PCT, g[6] if len(g) > 6 else 25)
+        ctx.set_tuning(api.PT_TUNE_EXTEND_FETCH_MIN, g[0]); ctx.set_tuning(api.PT_TUNE_EXTEND_POSTPONE_PCT, g[1])
+        ctx.set_tuning(api.PT_TUNE_EXTEND_LDS_STACK, g[3] if g[3] else 6)
+        ctx.set_tuning(api.PT_TUNE_EXTEND_BLOCKS_PER_CU, g[2])
+        ctx.set_tuning(api.PT_TUNE_EXTEND_DEFER, g[4] if g[4] else 4)
+        ctx.set_tuning(api.PT_TUNE_EXTEND_TOP_NODES, g[5] if len(g) > 5 else 73)
+        ctx.set_tuning(api.PT_TUNE_EXTEND_CONTINUE_PCT, g[6] if len(g) > 6 else 25)
         ctx.render(c, W, H, 0, SPP); ctx.stats_reset()
         ctx.render(c, W, H, 0, 2 * SPP)
         s = ctx.stats()

@@ -14,7 +14,7 @@ ctx.set_option(api.PT_OPT_SAMPLES_PER_BATCH, SPP)
 ctx.set_option(api.PT_OPT_COUNT_TRAVERSAL, 1)
 ctx.set_option(api.PT_OPT_TIME_KERNELS, 1)
 for fm, pp, dq in [(16, 35, 0), (16, 20, 4), (16, 35, 4), (16, 50, 4), (16, 65, 4), (16, 50, 2), (16, 50, 8), (8, 50, 4), (24, 50, 4)]:
-    ctx.set_option(api.PT_OPT_EXTEND_FETCH_MIN, fm); ctx.set_option(api.PT_OPT_EXTEND_POSTPONE_PCT, pp); ctx.set_option(api.PT_OPT_EXTEND_DEFER, dq)
+    ctx.set_tuning(api.PT_TUNE_EXTEND_FETCH_MIN, fm); ctx.set_tuning(api.PT_TUNE_EXTEND_POSTPONE_PCT, pp); ctx.set_tuning(api.PT_TUNE_EXTEND_DEFER, dq)
     ctx.stats_reset(); ctx.render(c, W, H, 0, SPP); s = ctx.stats()
     ctx.set_option(api.PT_OPT_COUNT_TRAVERSAL, 0); ctx.render(c, W, H, 0, SPP); ctx.stats_reset(); ctx.render(c, W, H, 0, 2 * SPP); t = ctx.stats()
     ctx.set_option(api.PT_OPT_COUNT_TRAVERSAL, 1)
