@@ -407,11 +407,11 @@ def main():
     # ---- which samples this rank renders in the timed region ----
     strong = world > 1 and not args.weak
     total_spp = args.total_spp if args.total_spp > 0 else K * SPP
-    if not strong:
-        # every rank: K steps of SPP samples from its own contiguous block (weak scaling; the whole job at N = 1)
+    if args.weak and world > 1:
+        # every rank: K steps of SPP samples from its own contiguous block
         my_first, my_count = rank * K * SPP, K * SPP
         job_spp = world * K * SPP
-    else:
+    else:   # the job's samples (K x SPP, or --total-spp) partitioned over the ranks; at N = 1 the one rank takes them all
         my_first, my_count = ptdist.partition_samples(total_spp, world, rank)
         job_spp = total_spp
     warm_first = job_spp + rank * max(1, WU) * SPP          # warm-up samples: outside the job's sample range

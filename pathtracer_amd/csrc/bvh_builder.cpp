@@ -173,8 +173,8 @@ class SplitBuilder {
     if (pr.b != 0xFFFFFFFFu) any = clip_triangle(verts_ + (size_t)pr.b * 9, axis, lo, hi, blo, bhi) || any;
     if (!any) return false;
     for (int k = 0; k < 3; ++k) {
-      out.lo[k] = std::max(r.lo[k], round_down(blo[k]) - pad_);
-      out.hi[k] = std::min(r.hi[k], round_up(bhi[k]) + pad_);
+      out.lo[k] = std::max(r.lo[k], round_down(blo[k]));
+      out.hi[k] = std::min(r.hi[k], round_up(bhi[k]));
     }
     return out.valid();
   }
@@ -224,7 +224,10 @@ class SplitBuilder {
     });
     Bounds bb = pb[0];
     for (int s = 1; s < sl0; ++s) { bb.box.grow(pb[s].box); bb.cen.grow(pb[s].cen); }
-    for (int a = 0; a < 3; ++a) { nd.lo[a] = bb.box.lo[a]; nd.hi[a] = bb.box.hi[a]; }
+    // References carry the exact (outward-rounded) boxes of their pieces; the conservative pad goes onto the NODE boxes only.
+    // Padding the references themselves would wipe out their centres where the pad exceeds a coordinate (the pad is
+    // relative to the scene's magnitude: a scene spanning 1e36 pads by 4e30, and every centre of a small triangle reads 0).
+    for (int a = 0; a < 3; ++a) { nd.lo[a] = bb.box.lo[a] - pad_; nd.hi[a] = bb.box.hi[a] + pad_; }
     nd.left = 0;
     nd.count = 1;
     if (n <= 1) {
@@ -609,7 +612,6 @@ void build_bvh8(const float* verts, uint32_t n, Bvh8& out, int num_threads, int 
         p.hi[a] = std::max(p.hi[a], std::max(v[a], std::max(v[3 + a], v[6 + a])));
       }
     }
-    for (int a = 0; a < 3; ++a) { p.lo[a] -= pad; p.hi[a] += pad; }
     weight[k] = refs[k].b == 0xFFFFFFFFu ? 1.0f : 1.6f;
     if (refs[k].b != 0xFFFFFFFFu) out.num_pairs++;
   }

@@ -1,4 +1,5 @@
 """Shared helpers for the tests and the fixture generator (host-side only: no GPU, no oracle import)."""
+import os
 import math
 
 import numpy as np
@@ -116,3 +117,22 @@ def random_rays(seed, n, lo, hi, tmin=0.0, tmax=10000.0):
     rays["tmin"] = tmin
     rays["tmax"] = tmax
     return rays
+
+
+import contextlib
+
+
+@contextlib.contextmanager
+def object_splits_only():
+    """Scenes created inside are built WITHOUT spatial splits (PT_BVH_SPLIT_BUDGET=0, read by the builder at scene
+    creation): the tests of the deep-stack / spill paths need the degenerate, very deep hierarchy that spatial splits
+    would repair (depth 8 instead of > 24 on the nested-triangle scene)."""
+    old = os.environ.get("PT_BVH_SPLIT_BUDGET")
+    os.environ["PT_BVH_SPLIT_BUDGET"] = "0"
+    try:
+        yield
+    finally:
+        if old is None:
+            del os.environ["PT_BVH_SPLIT_BUDGET"]
+        else:
+            os.environ["PT_BVH_SPLIT_BUDGET"] = old

@@ -9,7 +9,7 @@ import pytest
 
 from pathtracer_amd import api, scenes
 from pathtracer_amd.context import SceneData
-from tests.common import cornell_consts, function_inputs, lookat_consts, random_rays, rel_mse
+from tests.common import cornell_consts, function_inputs, lookat_consts, object_splits_only, random_rays, rel_mse
 
 pytestmark = pytest.mark.gpu
 G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
@@ -244,7 +244,8 @@ def test_deep_hierarchy_with_every_stack_configuration(ctx, oracle):
     """A hierarchy far deeper than the LDS part of the traversal stack: the LDS clamp, the spill region and the
     deferred queue must all give the brute-force answer."""
     sc, rays = deep_hierarchy_scene()
-    ctx.scene_create(sc)
+    with object_splits_only():      # with spatial splits the builder turns this scene into a balanced tree of depth 8
+        ctx.scene_create(sc)
     osc = oracle.scene(sc)
     depth = ctx.scene_info().bvh_max_depth
     assert depth >= 24, depth         # 2*depth+2 stack entries + 16 deferred: beyond what the kernel keeps in LDS
@@ -520,17 +521,20 @@ def test_street_hard_sah_hostile_scene_hits_and_image_match_oracle(ctx, oracle):
     atm = oracle.earth_atmosphere()
     ctx.sky_set(atm)
     olut = oracle.transmittance_lut(atm)
-    w, h = 160, 90
+    # 16 spp: in this scene of slivers and litter a last-ulp difference of a bounce direction (ocml vs libm sin/cos/pow) lands
+    # on another triangle more often than in the grid scenes (observed: 5 of 220,455 rays at 2 spp), and with few samples per
+    # pixel those few paths carry the whole difference (2 spp: relMSE 2.9e-4; it falls as 1/spp)
+    w, h, spp = 160, 90, 16
     c = lookat_consts(w, h, scenes.STREET_HARD_CAM, depth=8)
     ctx.accum_reset(w, h)
     ctx.stats_reset()
-    ctx.render(c, w, h, 0, 2)
+    ctx.render(c, w, h, 0, spp)
     img = ctx.accum_read()
     st = ctx.stats()
-    acc, ost, _ = osc.render(c, w, h, 0, 2, lut=olut)
-    print("street_hard rays", st.rays, ost["rays"], "sky", st.sky_misses, ost["sky_misses"], "relMSE", rel_mse(img, acc / 2.0))
+    acc, ost, _ = osc.render(c, w, h, 0, spp, lut=olut)
+    print("street_hard rays", st.rays, ost["rays"], "sky", st.sky_misses, ost["sky_misses"], "relMSE", rel_mse(img, acc / spp))
     assert abs(st.rays - ost["rays"]) <= 3e-4 * ost["rays"]
-    assert rel_mse(img, acc / 2.0) < 1e-4, rel_mse(img, acc / 2.0)
+    assert rel_mse(img, acc / spp) < 1e-4, rel_mse(img, acc / spp)
 
 
 def test_stats_struct_is_versioned_by_size(ctx):

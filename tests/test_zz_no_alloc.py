@@ -56,7 +56,9 @@ def test_noalloc_trace_matches_allocating_entry_point(ctx):
     # a deep hierarchy exercises the spill region that lives in the static scratch
     from tests.test_gpu_parity import deep_hierarchy_scene
     deep, rays = deep_hierarchy_scene()
-    ctx.scene_create(deep)
+    from tests.common import object_splits_only
+    with object_splits_only():
+        ctx.scene_create(deep)
     assert ctx.scene_info().bvh_max_depth >= 24
     a, b = both(rays)
     assert (a[:, 3] != api.PT_MISS).mean() > 0.5
