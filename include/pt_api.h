@@ -214,6 +214,11 @@ enum {
   PT_OPT_FUSED_PRIMARY = 14,       /* 0/1 (default 1): pt_render computes primary rays inside the traversal and shading kernels
                                       (RayGen's ray set-up, PathTracing.hlsl:40-61) instead of writing them to the bounce-0 queue
                                       and reading them back: 160 B of memory traffic per path less, results bit-identical */
+  PT_OPT_FRAME_LANES = 16,         /* 1..8 (default 6): small pt_render calls (one batch of < 2^20 paths: the reference's interactive loop, one
+                                      640x360 sample per RenderRT call, PathTracer.cpp:573-595) are queued round-robin on this many internal
+                                      streams with their own wavefront state, so consecutive calls overlap on the GPU; their resolves stay
+                                      on the ctx stream in call order, so the target is bit-identical to 1 (= every call serial on the ctx
+                                      stream). Each lane in use holds its own queues and ~150 MB of traversal-stack spill region. */
   PT_OPT_PRIMARY_PACKET = 15       /* which kernel traces the fused primaries of pt_render (coherent 8x8-pixel tiles): 0 = the general per-lane
                                       traversal, 1 = one BVH walk per wave with wave-uniform node fetches (k_extend_packet), 2 (default) = the
                                       faster of the two, timed once per scene and frame size on <= 2^24 primaries. That FIRST pt_render call

@@ -38,6 +38,7 @@ PT_OPT_RUSSIAN_ROULETTE = 10
 PT_OPT_PIPELINE = 11
 PT_OPT_FUSED_PRIMARY = 14
 PT_OPT_PRIMARY_PACKET = 15
+PT_OPT_FRAME_LANES = 16
 
 # include/pt_api_tuning.h: schedule knobs of the traversal kernel, set through pt_debug_set_tuning (tools and tests only)
 PT_TUNE_EXTEND_FETCH_MIN = 5

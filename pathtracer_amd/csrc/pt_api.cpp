@@ -6,6 +6,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <cmath>
 #include <string>
@@ -68,6 +69,29 @@ struct pt_ctx {
   hipStream_t stream2 = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   bool pipeline = false;
+  // Frame lanes (PT_OPT_FRAME_LANES): the reference's interactive loop calls RenderRT once per frame with ONE sample per
+  // pixel (PathTracer.cpp:573-595) — at 640x360 a batch of 230 k paths whose dozen kernels each run at latency, not at
+  // throughput, with the GPU nearly empty. Such small pt_render calls are issued round-robin onto a few internal streams
+  // with their own wavefront state, so consecutive calls overlap; only the resolves (the accumulation target's
+  // read-modify-write) stay on the ctx stream, in call order, so the target is bit-identical to the serial schedule.
+  static constexpr int kMaxFrameLanes = 8;
+  struct FrameLane {
+    WavefrontBuffers wb;
+    std::vector<void*> allocs;
+    uint2* spill = nullptr;            // traversal-stack spill region of this lane's extend launches
+    hipStream_t stream = nullptr;
+    hipEvent_t ev_done = nullptr;      // lane stream: everything up to k_sky of the lane's current call
+    hipEvent_t ev_resolved = nullptr;  // ctx stream: the resolve that consumed the lane's path state
+    bool resolve_recorded = false;
+    uint64_t seen_epoch = 0;
+  };
+  FrameLane fl[kMaxFrameLanes];
+  int frame_lanes = 6;                 // PT_OPT_FRAME_LANES (1 = off). 640x360 atrium, ms per 1-spp call: 1.10 / 0.61 / 0.61 / 0.45 / 0.49 at 1 / 2 / 4 / 6 / 8 lanes
+                                       // (tools/exp_frame_lanes.py; the streams share 4 hardware queues, hence the steps)
+  int fl_next = 0;
+  uint64_t fork_epoch = 1;             // bumped by whatever queues work on the ctx stream that lane kernels depend on (scene, sky LUT, stream change)
+  hipEvent_t ev_epoch = nullptr;
+  const WavefrontBuffers* last_wb = nullptr;   // wavefront state of the last render call (pt_debug_read_queue)
   bool fused_primary = PT_DEFAULT_FUSED_PRIMARY != 0;   // PT_OPT_FUSED_PRIMARY
   int primary_packet = 2;             // PT_OPT_PRIMARY_PACKET: 0 = k_extend, 1 = k_extend_packet (one BVH walk per wave), 2 = whichever is
                                       // faster on this scene at this frame size (timed once, calibrate_primary_kernel)
@@ -217,6 +241,33 @@ int ensure_lane2(pt_ctx* ctx, uint64_t paths) {
   return ensure_wavefront_for(ctx, ctx->wb2, ctx->wb2_allocs, paths);
 }
 
+size_t spill_region_entries(const pt_ctx* ctx) {   // uint2 entries: the largest persistent grid ever launched (16 blocks per CU x 4 waves)
+  return (size_t)ctx->cfg.num_cus * 16u * 4u * ctx->ds.stack_entries * 64u;
+}
+
+int ensure_frame_lane(pt_ctx* ctx, pt_ctx::FrameLane& L, uint64_t paths) {
+  if (!L.stream) {
+    PT_HIP(hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
+    PT_HIP(hipEventCreateWithFlags(&L.ev_done, hipEventDisableTiming));
+    PT_HIP(hipEventCreateWithFlags(&L.ev_resolved, hipEventDisableTiming));
+  }
+  if (!ctx->ev_epoch) PT_HIP(hipEventCreateWithFlags(&ctx->ev_epoch, hipEventDisableTiming));
+  int rc = ensure_wavefront_for(ctx, L.wb, L.allocs, paths);   // (re-allocation synchronises the ctx stream, which waits on every lane)
+  if (rc != PT_OK) return rc;
+  if (!L.spill) {
+    if ((rc = dev_alloc(ctx, &L.spill, spill_region_entries(ctx), nullptr))) return rc;
+  }
+  return PT_OK;
+}
+
+// Scene or stream changes: the lanes' spill regions belong to the old scene's stack depth
+void release_frame_lane_spills(pt_ctx* ctx) {
+  for (auto& L : ctx->fl) {
+    if (L.stream) (void)hipStreamSynchronize(L.stream);
+    if (L.spill) { (void)hipFree(L.spill); L.spill = nullptr; }
+  }
+}
+
 int ensure_tmp(pt_ctx* ctx, uint64_t rays) {
   if (ctx->tmp_capacity >= rays) return PT_OK;
   PT_HIP(hipStreamSynchronize(ctx->stream));
@@ -278,8 +329,8 @@ int check_consts(pt_ctx* ctx, const PtRtConsts* c, bool need_sky) {
 }
 
 void extend_one(pt_ctx* ctx, const float4* ro, const float4* rd, uint32_t stride, float4* hits, const uint32_t* count, uint32_t* cursor, int bounce = 0,
-                bool any_hit = false, int lane = 0, const float4* primary_gen = nullptr, bool packet = false) {
-  const hipStream_t st = lane ? ctx->stream2 : ctx->stream;
+                bool any_hit = false, int lane = 0, const float4* primary_gen = nullptr, bool packet = false, uint64_t max_rays = 0) {
+  const hipStream_t st = lane >= 2 ? ctx->fl[lane - 2].stream : (lane ? ctx->stream2 : ctx->stream);
   std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
   if (ctx->time_kernels) {
     ev = get_event_pair(ctx);
@@ -290,6 +341,15 @@ void extend_one(pt_ctx* ctx, const float4* ro, const float4* rd, uint32_t stride
       ctx->packet_blocks = ctx->cfg.num_cus * std::max(1, std::min(8, extend_packet_occupancy_blocks(ctx->ds.stack_entries, ctx->ds.paired)));
     launch_extend_packet(ctx->ds, ro, rd, hits, count, cursor, ctx->packet_blocks, st, primary_gen);
     ctx->packet_launches++;
+  } else if (lane >= 2) {
+    // frame lane: a small queue (at most max_rays rays) on a grid cut to two 64-ray claims per wave, so that the extend
+    // launches of several frames in flight are resident side by side instead of one persistent grid filling every CU
+    DeviceScene ds2 = ctx->ds;
+    ds2.spill = ctx->fl[lane - 2].spill;
+    LaunchCfg cfg2 = ctx->cfg;
+    const uint64_t grid_div = 512u;   // rays per block: 256 / 512 / 1024 / 2048 measured, 512 best by 5-8 %
+    if (max_rays) cfg2.extend_blocks = (int)std::min<uint64_t>((uint64_t)cfg2.extend_blocks, std::max<uint64_t>((uint64_t)cfg2.num_cus, (max_rays + grid_div - 1) / grid_div));
+    launch_extend(ds2, ro, rd, stride, hits, count, cursor, ctx->fl[lane - 2].wb.stats, ctx->count_traversal, any_hit, cfg2, st, primary_gen);
   } else if (lane) {
     DeviceScene ds2 = ctx->ds;
     ds2.spill = ctx->spill2;
@@ -398,6 +458,14 @@ int pt_destroy(pt_ctx* ctx) {
   if (ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);
   free_list(ctx->wb_allocs);
   free_list(ctx->wb2_allocs);
+  release_frame_lane_spills(ctx);
+  for (auto& L : ctx->fl) {
+    free_list(L.allocs);
+    if (L.ev_done) (void)hipEventDestroy(L.ev_done);
+    if (L.ev_resolved) (void)hipEventDestroy(L.ev_resolved);
+    if (L.stream) (void)hipStreamDestroy(L.stream);
+  }
+  if (ctx->ev_epoch) (void)hipEventDestroy(ctx->ev_epoch);
   if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
   if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
   if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
@@ -420,6 +488,7 @@ int pt_set_stream(pt_ctx* ctx, void* hip_stream) {
   PT_REQUIRE_CTX();
   PT_HIP(hipStreamSynchronize(ctx->stream));
   ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+  ctx->fork_epoch++;
   return PT_OK;
 }
 
@@ -443,6 +512,10 @@ int pt_set_option(pt_ctx* ctx, int option, int64_t value) {
     case PT_OPT_SKY_MODE:
       if (value != 0 && value != 1) return ctx->fail(PT_ERR_UNSUPPORTED, "sky mode must be 0 (ray-march on every miss) or 1 (direction LUT)");
       ctx->sky_mode = (int)value;
+      return PT_OK;
+    case PT_OPT_FRAME_LANES:
+      if (value < 1 || value > pt_ctx::kMaxFrameLanes) return ctx->fail(PT_ERR_INVALID_ARG, "PT_OPT_FRAME_LANES must be 1..8");
+      ctx->frame_lanes = (int)value;
       return PT_OK;
     case PT_OPT_PRIMARY_PACKET: ctx->primary_packet = value < 0 ? 0 : (value > 2 ? 2 : (int)value); return PT_OK;
     case PT_OPT_FUSED_PRIMARY:
@@ -577,11 +650,12 @@ int pt_scene_create(pt_ctx* ctx, const PtMeshDesc* meshes, uint32_t num_meshes, 
     return ctx->fail(PT_ERR_UNSUPPORTED, "BVH deeper than the traversal stack supports (" + std::to_string(bvh.max_depth) + " levels)");
   {
     // spill region sized for the largest persistent grid we ever launch (16 blocks per CU x 4 waves)
-    const size_t waves = (size_t)ctx->cfg.num_cus * 16u * 4u;
     uint2* d_spill = nullptr;
-    if ((rc = dev_alloc(ctx, &d_spill, waves * ctx->ds.stack_entries * 64u, &ctx->scene_allocs))) return rc;
+    if ((rc = dev_alloc(ctx, &d_spill, spill_region_entries(ctx), &ctx->scene_allocs))) return rc;
     ctx->ds.spill = d_spill;
-    if ((rc = dev_alloc(ctx, &ctx->spill2, waves * ctx->ds.stack_entries * 64u, &ctx->scene_allocs))) return rc;   // pipeline lane 2
+    if ((rc = dev_alloc(ctx, &ctx->spill2, spill_region_entries(ctx), &ctx->scene_allocs))) return rc;   // pipeline lane 2
+    release_frame_lane_spills(ctx);   // re-allocated for this scene's stack depth on their next use
+    ctx->fork_epoch++;
   }
   ctx->cfg.extend_blocks = extend_grid(ctx);
   ctx->instance_material = fs.instance_material;
@@ -632,6 +706,7 @@ int pt_scene_set_material_ext(pt_ctx* ctx, const PtMaterialExt* ext, uint32_t nu
   }
   if (!rows.empty()) PT_HIP(hipMemcpy(ctx->instance_ext, rows.data(), rows.size() * 4, hipMemcpyHostToDevice));
   ctx->ds.instance_ext = ctx->instance_ext;
+  ctx->fork_epoch++;
   return PT_OK;
 }
 
@@ -657,6 +732,7 @@ int pt_sky_set(pt_ctx* ctx, const PtAtmosphere* atmosphere) {
   }
   launch_transmittance_lut(*atmosphere, ctx->lut, ctx->stream);
   PT_HIP(hipGetLastError());
+  ctx->fork_epoch++;   // frame lanes must not read the LUT before this kernel has run
   ctx->has_sky = true;
   return PT_OK;
 }
@@ -764,6 +840,57 @@ int pt_render(pt_ctx* ctx, const PtRtConsts* consts, uint32_t width, uint32_t he
   uint64_t spb = default_batch ? std::max<uint64_t>(1, (1ull << 27) / wh) : (uint64_t)ctx->samples_per_batch;
   spb = std::min<uint64_t>(spb, num_samples);
   spb = std::min<uint64_t>(spb, std::max<uint64_t>(1, ((1ull << 31) - 1) / wh));
+  // Small frames (the reference's interactive loop: one 640x360 sample per RenderRT call) go round-robin onto the frame
+  // lanes, see pt_ctx::FrameLane: this call's kernels are queued on a lane stream and overlap the previous calls', only
+  // its resolve is queued on the ctx stream. Not with per-kernel timing / counting (their figures assume one kernel at a
+  // time), the two-lane pipeline (large batches) or the per-call sky-view LUT (one shared table).
+  if (ctx->frame_lanes > 1 && num_samples <= spb && wh * num_samples < (1ull << 20) && !ctx->time_kernels && !ctx->count_traversal &&
+      !(ctx->sky_mode == 1 && consts->mySampleSky)) {
+    const int li = ctx->fl_next;
+    pt_ctx::FrameLane& L = ctx->fl[li];
+    if ((rc = ensure_frame_lane(ctx, L, wh * num_samples)) != PT_OK) return rc;
+    const bool fused = ctx->fused_primary;
+    bool packet = fused && ctx->primary_packet == 1;
+    if (fused && ctx->primary_packet == 2) {
+      if (ctx->packet_choice < 0 || ctx->packet_choice_w != width || ctx->packet_choice_h != height) {
+        if ((rc = ensure_wavefront(ctx, wh * num_samples)) != PT_OK) return rc;
+        if ((rc = calibrate_primary_kernel(ctx, *consts, width, height, first_sample, num_samples)) != PT_OK) return rc;
+      }
+      packet = ctx->packet_choice == 1;
+    }
+    ctx->fl_next = (li + 1) % ctx->frame_lanes;
+    ctx->last_render_fused = fused;
+    ctx->last_wb = &L.wb;
+    if (L.seen_epoch != ctx->fork_epoch) {   // scene / sky LUT / stream changed since this lane last ran: order it behind the ctx stream once
+      PT_HIP(hipEventRecord(ctx->ev_epoch, ctx->stream));
+      PT_HIP(hipStreamWaitEvent(L.stream, ctx->ev_epoch, 0));
+      L.seen_epoch = ctx->fork_epoch;
+    } else if (L.resolve_recorded) {         // the lane's path state is free once the resolve that read it has run
+      PT_HIP(hipStreamWaitEvent(L.stream, L.ev_resolved, 0));
+    }
+    const uint32_t bounces = consts->myMaxRecursionDepth + 1;
+    const uint32_t k = num_samples;
+    PT_HIP(hipMemsetAsync(L.wb.counters, 0, CTR_WORDS * sizeof(uint32_t), L.stream));
+    if (fused) launch_primary_setup(*consts, L.wb, width, height, first_sample, k, L.stream);
+    else launch_generate(*consts, L.wb, width, height, first_sample, k, L.stream);
+    for (uint32_t b = 0; b < bounces; ++b) {
+      const int in = (int)(b & 1u);
+      extend_one(ctx, L.wb.ray_o[in], L.wb.ray_d[in], 1, L.wb.hits, L.wb.counters + CTR_AT(CTR_QCOUNT0 + b), L.wb.counters + CTR_AT(CTR_WORK0 + b), (int)b, false,
+                 2 + li, (fused && b == 0) ? L.wb.gen : nullptr, /*packet=*/packet && b == 0, /*max_rays=*/wh * k);
+      launch_shade(*consts, ctx->ds, L.wb, (int)b, width, height, first_sample, wh * k, ctx->russian_roulette, ctx->cfg, L.stream, fused);
+    }
+    if (consts->mySampleSky) launch_sky(*consts, ctx->lut, nullptr, L.wb, wh * k, ctx->cfg, L.stream);
+    PT_HIP(hipEventRecord(L.ev_done, L.stream));
+    PT_HIP(hipStreamWaitEvent(ctx->stream, L.ev_done, 0));
+    launch_resolve(L.wb, ctx->accum, width, height, k, bounces, ctx->stream);   // call order == sample order on the ctx stream
+    PT_HIP(hipEventRecord(L.ev_resolved, ctx->stream));
+    L.resolve_recorded = true;
+    PT_HIP(hipGetLastError());
+    ctx->num_samples += num_samples;
+    return PT_OK;
+  }
+  ctx->last_wb = &ctx->wb;
+
   // Two pipeline lanes: a batch of k >= 2 samples is split into a lower and an upper half that run on two streams with
   // their own queues, so one half's shade kernels and kernel drains run under the other half's extend. The halves are
   // resolved in sample order on the ctx stream, so the target is bit-identical to the single-lane result.
@@ -865,6 +992,7 @@ int pt_render_ao(pt_ctx* ctx, const PtRtConsts* consts, uint32_t width, uint32_t
     PT_HIP(hipMemsetAsync(ctx->wb.counters, 0, CTR_WORDS * sizeof(uint32_t), ctx->stream));
     launch_generate(*consts, ctx->wb, width, height, first_sample + s, 1, ctx->stream);
     ctx->last_render_fused = false;
+    ctx->last_wb = &ctx->wb;
     extend_one(ctx, ctx->wb.ray_o[0], ctx->wb.ray_d[0], 1, ctx->wb.hits, ctx->wb.counters + CTR_AT(CTR_QCOUNT0), ctx->wb.counters + CTR_AT(CTR_WORK0), 0);
     launch_ao_primary(*consts, ctx->wb, wh, ctx->cfg, ctx->stream);
     launch_ao_rays(*consts, ctx->ds, ctx->wb, ctx->ao_o, ctx->ao_d, width, height, first_sample + s, wh, ctx->cfg, ctx->stream);
@@ -928,6 +1056,7 @@ int pt_primary_hits(pt_ctx* ctx, const PtRtConsts* consts, uint32_t width, uint3
   PT_HIP(hipMemsetAsync(ctx->wb.counters, 0, CTR_WORDS * sizeof(uint32_t), ctx->stream));
   launch_generate(*consts, ctx->wb, width, height, sample, 1, ctx->stream);
   ctx->last_render_fused = false;
+  ctx->last_wb = &ctx->wb;
   extend_one(ctx, ctx->wb.ray_o[0], ctx->wb.ray_d[0], 1, ctx->wb.hits, ctx->wb.counters + CTR_AT(CTR_QCOUNT0), ctx->wb.counters + CTR_AT(CTR_WORK0));
   PT_HIP(hipGetLastError());
   PT_HIP(hipMemcpyAsync(hits, ctx->wb.hits, wh * sizeof(PtHit), hipMemcpyDeviceToHost, ctx->stream));
@@ -1060,20 +1189,21 @@ int pt_debug_eval(pt_ctx* ctx, int fn, const PtRtConsts* consts, const float* in
 
 int pt_debug_read_queue(pt_ctx* ctx, uint32_t bounce, PtRay* host_rays, uint64_t capacity, uint64_t* count_out) {
   PT_REQUIRE_CTX();
-  if (!ctx->wb.counters || !count_out || bounce > 62) return ctx->fail(PT_ERR_INVALID_ARG, "no wavefront state or bad arguments");
+  const WavefrontBuffers& lw = ctx->last_wb ? *ctx->last_wb : ctx->wb;   // a small frame may have run on a frame lane
+  if (!lw.counters || !count_out || bounce > 62) return ctx->fail(PT_ERR_INVALID_ARG, "no wavefront state or bad arguments");
   if (bounce == 0 && ctx->last_render_fused)
     return ctx->fail(PT_ERR_UNSUPPORTED, "the bounce-0 queue is not materialised under PT_OPT_FUSED_PRIMARY (set it to 0 before pt_render)");
   PT_HIP(hipStreamSynchronize(ctx->stream));
   uint32_t n = 0;
-  PT_HIP(hipMemcpy(&n, ctx->wb.counters + CTR_AT(CTR_QCOUNT0 + bounce), sizeof(n), hipMemcpyDeviceToHost));
+  PT_HIP(hipMemcpy(&n, lw.counters + CTR_AT(CTR_QCOUNT0 + bounce), sizeof(n), hipMemcpyDeviceToHost));
   *count_out = n;
   if (!host_rays) return PT_OK;
   if (capacity < n) return ctx->fail(PT_ERR_INVALID_ARG, "host array too small");
   std::vector<float4> o(n), d(n);
   const int buf = (int)(bounce & 1u);
   if (n) {
-    PT_HIP(hipMemcpy(o.data(), ctx->wb.ray_o[buf], (size_t)n * sizeof(float4), hipMemcpyDeviceToHost));
-    PT_HIP(hipMemcpy(d.data(), ctx->wb.ray_d[buf], (size_t)n * sizeof(float4), hipMemcpyDeviceToHost));
+    PT_HIP(hipMemcpy(o.data(), lw.ray_o[buf], (size_t)n * sizeof(float4), hipMemcpyDeviceToHost));
+    PT_HIP(hipMemcpy(d.data(), lw.ray_d[buf], (size_t)n * sizeof(float4), hipMemcpyDeviceToHost));
   }
   for (uint32_t i = 0; i < n; ++i) {
     PtRay& r = host_rays[i];
@@ -1119,7 +1249,9 @@ int pt_stats_get(pt_ctx* ctx, PtStats* out) {
   memset(out, 0, sizeof(*out));
   PT_HIP(hipStreamSynchronize(ctx->stream));
   collect_events(ctx);
-  for (const WavefrontBuffers* wb : {&ctx->wb, &ctx->wb2}) {   // both pipeline lanes
+  std::vector<const WavefrontBuffers*> all_wb{&ctx->wb, &ctx->wb2};   // pipeline and frame lanes
+  for (const auto& L : ctx->fl) all_wb.push_back(&L.wb);
+  for (const WavefrontBuffers* wb : all_wb) {
     if (!wb->stats) continue;
     unsigned long long h[ST_WORDS];
     PT_HIP(hipMemcpy(h, wb->stats, sizeof(h), hipMemcpyDeviceToHost));
@@ -1159,6 +1291,8 @@ int pt_stats_reset(pt_ctx* ctx) {
   for (int b = 0; b < 16; ++b) ctx->extend_ms_bounce[b] = 0.0;
   if (ctx->wb.stats) PT_HIP(hipMemset(ctx->wb.stats, 0, ST_WORDS * sizeof(unsigned long long)));
   if (ctx->wb2.stats) PT_HIP(hipMemset(ctx->wb2.stats, 0, ST_WORDS * sizeof(unsigned long long)));
+  for (auto& L : ctx->fl)
+    if (L.wb.stats) PT_HIP(hipMemset(L.wb.stats, 0, ST_WORDS * sizeof(unsigned long long)));
   return PT_OK;
 }
 

@@ -730,6 +730,53 @@ def test_tonemapped_output_matches_oracle_image(ctx, cornell, oracle, tmp_path):
         pt.ctx.close()
 
 
+def test_frame_lanes_overlap_small_frames_with_identical_bits(ctx, oracle):
+    """PT_OPT_FRAME_LANES: the reference's interactive pattern (one sample per RenderRT call on a small target,
+    PathTracer.cpp:573-595) queued round-robin on 6 (or 3) internal streams must leave the same bits in the target as every call
+    serial on the ctx stream — across a camera change, a sky change (new LUT the lanes must wait for), a restart of the
+    accumulation and a scene change (deeper stack: the lanes' spill regions are re-made)."""
+    atm = oracle.earth_atmosphere()
+    w, h = 320, 180
+
+    def run(lanes):
+        ctx.set_option(api.PT_OPT_FRAME_LANES, lanes)
+        imgs = []
+        for sc, cam in ((scenes.atrium(1), scenes.ATRIUM_CAM), (scenes.random_triangle_soup(5, 20000), None)):
+            ctx.scene_create(sc)
+            ctx.sky_set(atm)
+            c = lookat_consts(w, h, cam) if cam else lookat_consts(w, h, {"eye": (5.0, 5.0, -8.0), "target": (5.0, 5.0, 5.0)})
+            ctx.accum_reset(w, h)
+            for i in range(9):
+                ctx.render(c, w, h, i, 1)                   # 9 calls on 4 lanes: every lane is re-used
+            c2 = lookat_consts(w, h, cam, depth=6) if cam else c
+            for i in range(9, 14):
+                ctx.render(c2, w, h, i, 1 + (i & 1))         # mixed 1- and 2-sample calls
+            atm2 = oracle.earth_atmosphere()
+            atm2.MiePhaseG = 0.6
+            ctx.sky_set(atm2)                                # lanes must not read the LUT before this kernel has run
+            for i in range(16, 20):
+                ctx.render(c2, w, h, i, 1)
+            imgs.append(ctx.accum_read_sum()[0].copy())
+            ctx.accum_reset(w, h)                            # restart: the memset is ordered against the lanes' resolves
+            for i in range(3):
+                ctx.render(c, w, h, i, 1)
+            imgs.append(ctx.accum_read_sum()[0].copy())
+            q = ctx.debug_read_queue(1)                      # the last call's queue lives in a lane's buffers
+            assert len(q) > 0
+        return imgs
+    try:
+        a = run(6)
+        c3 = run(3)
+        b = run(1)
+    finally:
+        ctx.set_option(api.PT_OPT_FRAME_LANES, 6)
+    for x, y, z in zip(a, b, c3):
+        assert np.isfinite(x).all() and x[..., :3].sum() > 0
+        assert np.array_equal(x.view(np.uint32), y.view(np.uint32)) and np.array_equal(z.view(np.uint32), y.view(np.uint32))
+    with pytest.raises(api.PtError):
+        ctx.set_option(api.PT_OPT_FRAME_LANES, 9)
+
+
 # ---------------------------------------------------------------------------------------------- bench launcher
 def test_bench_gpus_2_starts_two_ranks_by_itself():
     """`python bench.py --gpus 2` (the driver's form) must run TWO ranks: rehearsed on this one-GPU box with gloo and

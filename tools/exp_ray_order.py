@@ -1,6 +1,6 @@
 """What is ray ORDER worth to k_extend? Takes the real bounce-1 queue of the atrium (secondary rays in the order k_shade's
 compaction leaves them), re-orders it on the host in several ways and times pt_trace_rays_device on each.
-usage: python tools/exp_ray_order.py [atrium|street] [bounce]"""
+usage: python tools/exp_ray_order.py [atrium|street|street_hard|courtyard] [bounce]"""
 import sys, os, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -9,7 +9,8 @@ from pathtracer_amd import PathTracer, api, scenes
 wl = sys.argv[1] if len(sys.argv) > 1 else "atrium"
 bounce = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 W, H, SPP = 1920, 1080, 4
-scene, cam, depth = {"atrium": (scenes.atrium, scenes.ATRIUM_CAM, 4), "street": (scenes.street, scenes.STREET_CAM, 8)}[wl]
+scene, cam, depth = {"atrium": (scenes.atrium, scenes.ATRIUM_CAM, 4), "street": (scenes.street, scenes.STREET_CAM, 8),
+                     "street_hard": (scenes.street_hard, scenes.STREET_HARD_CAM, 8), "courtyard": (scenes.courtyard, scenes.COURTYARD_CAM, 16)}[wl]
 pt = PathTracer(0, W, H); pt.myHalfResRender = False; pt.UpdateOutputTexture()
 pt.LoadScene(scene(), cam["eye"]); pt.myCamera.LookAt(cam["eye"], cam["target"])
 pt.mySampleSky = True; pt.myLightInstanceIdx = -1; pt.myMaxRecursionDepth = depth
