@@ -246,12 +246,19 @@ int pt_set_option(pt_ctx* ctx, int option, int64_t value);
 typedef struct PtMaterialExt {
   float roughness;          /* GGX alpha = max(roughness^2, 1e-3) */
   float metallic;           /* F0 = lerp(0.04, base, metallic); diffuse = base * (1 - metallic) */
-  uint32_t albedo_pattern;  /* 0 = none, 1 = checker (1 / 0.35), 2 = smooth value noise in [0.35, 1) */
+  uint32_t albedo_pattern;  /* 0 = none, 1 = checker (1 / 0.35), 2 = smooth value noise in [0.35, 1), 3 = the scene's albedo image
+                               (pt_scene_set_albedo_texture; factor 1 while none is set) */
   float pattern_scale;      /* uv multiplier */
   uint32_t flags;           /* PT_MAT_GGX */
   uint32_t reserved[3];
 } PtMaterialExt;
 int pt_scene_set_material_ext(pt_ctx* ctx, const PtMaterialExt* ext, uint32_t num_materials);
+/* Albedo image of the material extension (BASELINE C4 "textured GGX materials"; NOT in the reference, whose one DDS file
+ * is never sampled, PathTracer.cpp:435-436): width x height RGBA8 texels, row-major, R in the low byte. Materials with
+ * albedo_pattern == 3 multiply their base colour by the image sampled at uv * pattern_scale (repeat addressing, bilinear,
+ * texel centres at half-integer coordinates; definition: pathtracer_amd/csrc/ggx_device.h SampleAlbedoTexture). The library
+ * copies the texels; rgba8 == NULL removes the image. Belongs to the current scene (pt_scene_create drops it). */
+int pt_scene_set_albedo_texture(pt_ctx* ctx, const uint8_t* rgba8, uint32_t width, uint32_t height);
 
 /* ---- scene: replaces PathTracer::InitRtScene incl. the driver BLAS/TLAS build (PathTracer.cpp:171-339) ----
  * Flattens meshes x instances into world-space SoA triangle / vertex{normal,uv} / material buffers,

@@ -29,6 +29,8 @@ struct Scene {
   std::vector<float2> vertex_uv;         // VertexData.myUv
   std::vector<uint32_t> instance_material;  // InstanceData.myMaterialIndex (PathTracer.cpp:276-295)
   std::vector<PtMaterial> materials;     // MaterialData (PathTracer.cpp:318-329)
+  std::vector<uint32_t> albedo_tex;          // albedo pattern 3: RGBA8 image of the material extension (orc_scene_set_albedo_texture)
+  uint32_t tex_w = 0, tex_h = 0;
   std::vector<PtMaterialExt> materials_ext;  // material extension (include/pt_api.h), empty = none; NOT in the reference
   // BVH2
   struct Node { float lo[3], hi[3]; uint32_t left, count; };  // count>0: leaf, left = first index into order[]

@@ -30,6 +30,26 @@ static inline float AlbedoPattern(uint32_t pattern, float scale, float2 uv) {
   return 0.35f + 0.65f * (a + (b - a) * sy);
 }
 
+// Albedo pattern 3 (ggx_device.h SampleAlbedoTexture, operation by operation): RGBA8 image, repeat addressing, bilinear
+// filtering of the decoded texels, texel centres at half-integer coordinates.
+static inline float3 TexelRgb(const uint32_t* tex, uint32_t w, int x, int y) {
+  const uint32_t c = tex[(size_t)y * w + (uint32_t)x];
+  return float3{(float)(c & 0xffu) / 255.0f, (float)((c >> 8) & 0xffu) / 255.0f, (float)((c >> 16) & 0xffu) / 255.0f};
+}
+static inline int WrapTexel(int i, int n) { const int m = i % n; return m < 0 ? m + n : m; }
+static inline float3 SampleAlbedoTexture(const uint32_t* tex, uint32_t w, uint32_t h, float scale, float2 uv) {
+  if (tex == nullptr || w == 0u || h == 0u) return f3(1.0f);
+  const float px = uv.x * scale * (float)w - 0.5f, py = uv.y * scale * (float)h - 0.5f;
+  if (!(fabsf(px) < 1.0e9f) || !(fabsf(py) < 1.0e9f)) return f3(1.0f);
+  const float fx = floorf(px), fy = floorf(py);
+  const float tx = px - fx, ty = py - fy;
+  const int x0 = WrapTexel((int)fx, (int)w), y0 = WrapTexel((int)fy, (int)h);
+  const int x1 = x0 + 1 == (int)w ? 0 : x0 + 1, y1 = y0 + 1 == (int)h ? 0 : y0 + 1;
+  const float3 c00 = TexelRgb(tex, w, x0, y0), c10 = TexelRgb(tex, w, x1, y0), c01 = TexelRgb(tex, w, x0, y1), c11 = TexelRgb(tex, w, x1, y1);
+  const float3 a = c00 + (c10 - c00) * tx, b = c01 + (c11 - c01) * tx;
+  return a + (b - a) * ty;
+}
+
 static inline float3 SchlickF(float3 F0, float c) {
   const float m = 1.0f - saturate(c);
   const float m2 = m * m;

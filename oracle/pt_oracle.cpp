@@ -78,7 +78,10 @@ static inline void ClosestHit(const Scene& S, const PtRtConsts& c, const PtHit& 
       float2 uv;   // LoadInterpolatedVertexData weights (Common.hlsl:121-126), as for the normal
       uv.x = h.u * t0.x + h.v * t1.x + baryZ * t2.x;
       uv.y = h.u * t0.y + h.v * t1.y + baryZ * t2.y;
-      payload.myColor = payload.myColor * AlbedoPattern(e.albedo_pattern, e.pattern_scale, uv);
+      if (e.albedo_pattern == 3u)
+        payload.myColor = payload.myColor * SampleAlbedoTexture(S.albedo_tex.empty() ? nullptr : S.albedo_tex.data(), S.tex_w, S.tex_h, e.pattern_scale, uv);
+      else
+        payload.myColor = payload.myColor * AlbedoPattern(e.albedo_pattern, e.pattern_scale, uv);
     }
     payload.myGgx = (e.flags & PT_MAT_GGX_BIT) != 0u;
     payload.myRoughness = e.roughness;
@@ -349,6 +352,18 @@ int orc_scene_set_material_ext(void* s, const PtMaterialExt* ext, uint32_t n) {
   if (!ext || n == 0) { S.materials_ext.clear(); return 0; }
   if (n != S.materials.size()) return 1;
   S.materials_ext.assign(ext, ext + n);
+  return 0;
+}
+int orc_scene_set_albedo_texture(void* s, const uint8_t* rgba8, uint32_t w, uint32_t h) {
+  Scene& S = *(Scene*)s;
+  S.albedo_tex.clear();
+  S.tex_w = S.tex_h = 0;
+  if (!rgba8) return 0;
+  if (w == 0 || h == 0) return 1;
+  S.albedo_tex.resize((size_t)w * h);
+  memcpy(S.albedo_tex.data(), rgba8, (size_t)w * h * 4);
+  S.tex_w = w;
+  S.tex_h = h;
   return 0;
 }
 uint32_t orc_scene_num_triangles(void* s) { return (uint32_t)((Scene*)s)->tris.size(); }

@@ -156,6 +156,7 @@ SYMBOLS = {
     "pt_scene_create": (C.c_int, [_P, C.POINTER(PtMeshDesc), C.c_uint32, C.POINTER(PtInstanceDesc), C.c_uint32,
                                   C.POINTER(PtMaterial), C.c_uint32, C.c_uint32]),
     "pt_scene_set_material_ext": (C.c_int, [_P, C.POINTER(PtMaterialExt), C.c_uint32]),
+    "pt_scene_set_albedo_texture": (C.c_int, [_P, _P, C.c_uint32, C.c_uint32]),
     "pt_scene_info": (C.c_int, [_P, C.POINTER(PtSceneInfo)]),
     "pt_sky_set": (C.c_int, [_P, C.POINTER(PtAtmosphere)]),
     "pt_sky_lut_read": (C.c_int, [_P, _P]),

@@ -25,6 +25,8 @@ class SceneData:
         # optional material extension (not in the reference): one (roughness, metallic, albedo_pattern, pattern_scale,
         # flags) tuple per material, see include/pt_api.h PtMaterialExt
         self.materials_ext = None
+        # optional albedo image of that extension: (h, w, 4) uint8, sampled by materials with albedo_pattern 3
+        self.albedo_texture = None
 
     @property
     def num_triangles(self):
@@ -110,6 +112,17 @@ class Context:
         ext = pack_material_ext(scene)
         if ext is not None:
             self._ck(self.lib.pt_scene_set_material_ext(self.h, ext, len(ext)))
+        if getattr(scene, "albedo_texture", None) is not None:
+            self.scene_set_albedo_texture(scene.albedo_texture)
+
+    def scene_set_albedo_texture(self, rgba8):
+        """pt_scene_set_albedo_texture: (h, w, 4) uint8 image for albedo pattern 3, or None to remove it."""
+        if rgba8 is None:
+            self._ck(self.lib.pt_scene_set_albedo_texture(self.h, None, 0, 0))
+            return
+        img = np.ascontiguousarray(rgba8, dtype=np.uint8)
+        assert img.ndim == 3 and img.shape[2] == 4
+        self._ck(self.lib.pt_scene_set_albedo_texture(self.h, api.ptr(img), img.shape[1], img.shape[0]))
 
     def scene_set_material_ext(self, scene_or_none):
         ext = pack_material_ext(scene_or_none) if scene_or_none is not None else None

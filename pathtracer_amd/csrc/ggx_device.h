@@ -20,7 +20,7 @@ __device__ __forceinline__ float lattice01(int ix, int iy, uint32_t seed) {
   return uintToFloat(pcg4d_x(r));
 }
 
-// procedural albedo factor: 0 none, 1 checker, 2 smooth value noise
+// procedural albedo factor: 0 none, 1 checker, 2 smooth value noise (3 = image: SampleAlbedoTexture below)
 __device__ __forceinline__ float AlbedoPattern(uint32_t pattern, float scale, v2 uv) {
   if (pattern == 0u) return 1.0f;
   const float px = uv.x * scale, py = uv.y * scale;
@@ -33,6 +33,28 @@ __device__ __forceinline__ float AlbedoPattern(uint32_t pattern, float scale, v2
   const float v01 = lattice01(ix, iy + 1, 0x9E3779B9u), v11 = lattice01(ix + 1, iy + 1, 0x9E3779B9u);
   const float a = v00 + (v10 - v00) * sx, b = v01 + (v11 - v01) * sx;
   return 0.35f + 0.65f * (a + (b - a) * sy);
+}
+
+// Albedo pattern 3: an RGBA8 image (pt_scene_set_albedo_texture), repeat addressing, bilinear filtering of the decoded
+// texels (c / 255, R in the low byte as Decode_Unorm_RGBA), texel centres at half-integer coordinates; uv is multiplied by
+// the material's pattern_scale first. Plain fp32 multiply / add in this order, so the oracle reproduces it bit for bit.
+// No image set, or non-finite coordinates: factor 1.
+__device__ __forceinline__ v3 TexelRgb(const uint32_t* __restrict__ tex, uint32_t w, int x, int y) {
+  const uint32_t c = tex[(size_t)y * w + (uint32_t)x];
+  return mk3((float)(c & 0xffu) / 255.0f, (float)((c >> 8) & 0xffu) / 255.0f, (float)((c >> 16) & 0xffu) / 255.0f);
+}
+__device__ __forceinline__ int WrapTexel(int i, int n) { const int m = i % n; return m < 0 ? m + n : m; }
+__device__ __forceinline__ v3 SampleAlbedoTexture(const uint32_t* __restrict__ tex, uint32_t w, uint32_t h, float scale, v2 uv) {
+  if (tex == nullptr || w == 0u || h == 0u) return mk3(1.0f);
+  const float px = uv.x * scale * (float)w - 0.5f, py = uv.y * scale * (float)h - 0.5f;
+  if (!(fabsf(px) < 1.0e9f) || !(fabsf(py) < 1.0e9f)) return mk3(1.0f);
+  const float fx = floorf(px), fy = floorf(py);
+  const float tx = px - fx, ty = py - fy;
+  const int x0 = WrapTexel((int)fx, (int)w), y0 = WrapTexel((int)fy, (int)h);
+  const int x1 = x0 + 1 == (int)w ? 0 : x0 + 1, y1 = y0 + 1 == (int)h ? 0 : y0 + 1;
+  const v3 c00 = TexelRgb(tex, w, x0, y0), c10 = TexelRgb(tex, w, x1, y0), c01 = TexelRgb(tex, w, x0, y1), c11 = TexelRgb(tex, w, x1, y1);
+  const v3 a = c00 + (c10 - c00) * tx, b = c01 + (c11 - c01) * tx;
+  return a + (b - a) * ty;
 }
 
 __device__ __forceinline__ v3 SchlickF(v3 F0, float c) {

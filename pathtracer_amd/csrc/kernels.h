@@ -16,6 +16,8 @@ struct DeviceScene {
                                        // everything ClosestHit loads, in ONE 64-byte record (one dependent fetch instead of three)
   const float2* vertex_uv = nullptr;
   const float4* instance_ext = nullptr;  // material extension per instance (roughness, metallic, pattern scale, pattern | ggx << 8); null = none
+  const uint32_t* albedo_tex = nullptr;  // material extension, albedo pattern 3: RGBA8 image (pt_scene_set_albedo_texture), tex_w x tex_h texels
+  uint32_t tex_w = 0, tex_h = 0;
   float scene_mag = 0.0f;              // largest |coordinate| of the active triangles (overflow guard of the box test)
   uint32_t num_nodes = 0;              // BVH8 nodes in `nodes`
   uint32_t stack_entries = 0;          // stack entries per lane the traversal may need (2 per BVH level + 2)

@@ -545,7 +545,8 @@ __global__ void __launch_bounds__(PT_SHADE_THREADS, PT_SHADE_MIN_WAVES) k_shade(
             v2 uv;   // LoadInterpolatedVertexData weights (Common.hlsl:121-126), as for the normal
             uv.x = bu * t0.x + bv * t1.x + baryZ * t2.x;
             uv.y = bu * t0.y + bv * t1.y + baryZ * t2.y;
-            color = color * AlbedoPattern(bits & 0xffu, ext.z, uv);
+            if ((bits & 0xffu) == 3u) color = color * SampleAlbedoTexture(sc.albedo_tex, sc.tex_w, sc.tex_h, ext.z, uv);
+            else color = color * AlbedoPattern(bits & 0xffu, ext.z, uv);
           }
           ggx = ((bits >> 8) & PT_MAT_GGX_BIT) != 0u;
           roughness = ext.x;

@@ -45,6 +45,7 @@ struct pt_ctx {
   uint32_t num_materials = 0;
   uint64_t num_records = 0;                  // leaf records of the BVH (48-byte triangles or 64-byte pairs, ds.paired)
   float4* instance_ext = nullptr;
+  uint32_t* albedo_tex = nullptr;            // pt_scene_set_albedo_texture
   PtSceneInfo info{};
 
   // sky
@@ -455,6 +456,7 @@ int pt_destroy(pt_ctx* ctx) {
   for (auto& p : ctx->event_pool) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
   free_list(ctx->scene_allocs);
   if (ctx->instance_ext) (void)hipFree(ctx->instance_ext);
+  if (ctx->albedo_tex) (void)hipFree(ctx->albedo_tex);
   if (ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);
   free_list(ctx->wb_allocs);
   free_list(ctx->wb2_allocs);
@@ -580,6 +582,7 @@ int pt_scene_create(pt_ctx* ctx, const PtMeshDesc* meshes, uint32_t num_meshes, 
   PT_HIP(hipStreamSynchronize(ctx->stream));
   free_list(ctx->scene_allocs);
   if (ctx->instance_ext) { (void)hipFree(ctx->instance_ext); ctx->instance_ext = nullptr; }
+  if (ctx->albedo_tex) { (void)hipFree(ctx->albedo_tex); ctx->albedo_tex = nullptr; }
   ctx->has_scene = false;
   ctx->ds = DeviceScene();
 
@@ -689,7 +692,7 @@ int pt_scene_set_material_ext(pt_ctx* ctx, const PtMaterialExt* ext, uint32_t nu
   if (num_materials != ctx->num_materials) return ctx->fail(PT_ERR_SIZE_MISMATCH, "one PtMaterialExt per material of the scene is required");
   for (uint32_t m = 0; m < num_materials; ++m) {
     const PtMaterialExt& e = ext[m];
-    if (!(e.roughness >= 0.0f && e.roughness <= 1.0f) || !(e.metallic >= 0.0f && e.metallic <= 1.0f) || e.albedo_pattern > 2u ||
+    if (!(e.roughness >= 0.0f && e.roughness <= 1.0f) || !(e.metallic >= 0.0f && e.metallic <= 1.0f) || e.albedo_pattern > 3u ||
         !std::isfinite(e.pattern_scale) || (e.flags & ~PT_MAT_GGX) != 0u)
       return ctx->fail(PT_ERR_INVALID_ARG, "PtMaterialExt " + std::to_string(m) + ": roughness/metallic outside [0,1], unknown pattern or flag");
   }
@@ -707,6 +710,25 @@ int pt_scene_set_material_ext(pt_ctx* ctx, const PtMaterialExt* ext, uint32_t nu
   if (!rows.empty()) PT_HIP(hipMemcpy(ctx->instance_ext, rows.data(), rows.size() * 4, hipMemcpyHostToDevice));
   ctx->ds.instance_ext = ctx->instance_ext;
   ctx->fork_epoch++;
+  return PT_OK;
+}
+
+int pt_scene_set_albedo_texture(pt_ctx* ctx, const uint8_t* rgba8, uint32_t width, uint32_t height) {
+  PT_REQUIRE_CTX();
+  if (!ctx->has_scene) return ctx->fail(PT_ERR_NO_SCENE, "pt_scene_set_albedo_texture before pt_scene_create");
+  PT_HIP(hipStreamSynchronize(ctx->stream));   // (covers the frame lanes: their resolves are queued on the ctx stream)
+  if (ctx->albedo_tex) { (void)hipFree(ctx->albedo_tex); ctx->albedo_tex = nullptr; }
+  ctx->ds.albedo_tex = nullptr;
+  ctx->ds.tex_w = ctx->ds.tex_h = 0;
+  ctx->fork_epoch++;
+  if (!rgba8) return PT_OK;
+  if (width == 0 || height == 0 || width > 16384u || height > 16384u) return ctx->fail(PT_ERR_INVALID_ARG, "albedo image must be 1..16384 texels on each side");
+  int rc;
+  if ((rc = dev_alloc(ctx, &ctx->albedo_tex, (size_t)width * height, nullptr))) return rc;
+  PT_HIP(hipMemcpy(ctx->albedo_tex, rgba8, (size_t)width * height * 4, hipMemcpyHostToDevice));
+  ctx->ds.albedo_tex = ctx->albedo_tex;
+  ctx->ds.tex_w = width;
+  ctx->ds.tex_h = height;
   return PT_OK;
 }
 

@@ -664,17 +664,38 @@ def courtyard(seed=3, target_tris=10485760):
 COURTYARD_CAM = {"eye": (-34.0, 1.7, -24.0), "target": (10.0, 6.0, 8.0)}
 
 
+def albedo_image(seed=11, size=256):
+    """A procedural RGBA8 albedo image (size x size): staggered bricks with mortar lines, per-brick tint and fine grain —
+    the stand-in for a base-colour texture file (none ships with the reference; its one DDS is never sampled)."""
+    y, x = np.mgrid[0:size, 0:size]
+    bw, bh = size // 8, size // 16
+    row = y // bh
+    xs = (x + (row % 2) * (bw // 2)) % size
+    col = xs // bw
+    mortar = ((xs % bw) < 2) | ((y % bh) < 2)
+    tint = 0.55 + 0.45 * _rand01(seed, 1, (row * 131 + col).ravel()).reshape(size, size)
+    grain = 0.92 + 0.08 * _rand01(seed, 2, (y * size + x).ravel()).reshape(size, size)
+    rgb = np.stack([tint * grain, (0.8 * tint + 0.1) * grain, (0.65 * tint + 0.2) * grain], axis=-1)
+    rgb = np.where(mortar[..., None], 0.35, rgb)
+    img = np.empty((size, size, 4), dtype=np.uint8)
+    img[..., :3] = np.clip(np.floor(rgb * 255.0 + 0.5), 0, 255).astype(np.uint8)
+    img[..., 3] = 255
+    return img
+
+
 def with_material_ext(scene, seed=7):
-    """Attach the C4/C5 material extension (GGX + procedural albedo; not in the reference) to a scene: per material a
-    roughness in [0.08, 0.9], one in five metallic, albedo pattern cycling none / checker / value noise, two in three
-    shaded with GGX (the rest keep the reference's Lambert + Phong so both models are exercised)."""
+    """Attach the C4/C5 material extension (textured GGX; not in the reference) to a scene: per material a roughness in
+    [0.08, 0.9], one in five metallic, the albedo cycling none / checker / value noise / IMAGE (albedo_image, sampled
+    bilinearly at uv x scale), two in three shaded with GGX (the rest keep the reference's Lambert + Phong so both models
+    are exercised)."""
     n = len(scene.materials)
     i = np.arange(n)
     rough = 0.08 + 0.82 * _rand01(seed, 1, i)
     metal = (_rand01(seed, 2, i) < 0.2).astype(np.float64)
     scale = 2.0 + np.floor(6.0 * _rand01(seed, 3, i))
-    scene.materials_ext = [(float(rough[k]), float(metal[k]), int(k % 3), float(scale[k]), api.PT_MAT_GGX if k % 3 != 2 else 0)
+    scene.materials_ext = [(float(rough[k]), float(metal[k]), int(k % 4), float(scale[k]), api.PT_MAT_GGX if k % 3 != 2 else 0)
                            for k in range(n)]
+    scene.albedo_texture = albedo_image(seed + 4)
     return scene
 
 

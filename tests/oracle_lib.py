@@ -41,6 +41,8 @@ def load():
     lib.orc_scene_destroy.argtypes = [P]
     lib.orc_scene_set_material_ext.restype = C.c_int
     lib.orc_scene_set_material_ext.argtypes = [P, C.POINTER(api.PtMaterialExt), C.c_uint32]
+    lib.orc_scene_set_albedo_texture.restype = C.c_int
+    lib.orc_scene_set_albedo_texture.argtypes = [P, P, C.c_uint32, C.c_uint32]
     lib.orc_scene_num_triangles.restype = C.c_uint32
     lib.orc_scene_num_triangles.argtypes = [P]
     lib.orc_scene_triangle.argtypes = [P, C.c_uint32, P, P]
@@ -79,6 +81,9 @@ class OracleScene:
         ext = pack_material_ext(scene)
         if ext is not None:
             assert lib.orc_scene_set_material_ext(self.h, ext, len(ext)) == 0
+        if getattr(scene, "albedo_texture", None) is not None:
+            img = np.ascontiguousarray(scene.albedo_texture, dtype=np.uint8)
+            assert lib.orc_scene_set_albedo_texture(self.h, api.ptr(img), img.shape[1], img.shape[0]) == 0
 
     def __del__(self):
         if getattr(self, "h", None):

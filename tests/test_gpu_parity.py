@@ -954,6 +954,41 @@ def test_material_extension_image_matches_oracle(ctx, oracle):
 
 
 # ---------------------------------------------------------------------------------------------- two pipeline lanes
+def test_albedo_image_texture_matches_oracle(ctx, oracle):
+    """Albedo pattern 3 of the material extension (pt_scene_set_albedo_texture; BASELINE C4 "textured GGX materials", not in
+    the reference): a quad filling the view, its material sampling the brick image at uv x 3, lit by a constant white
+    environment (sky off, fallback emission 1), depth 1 — the image IS the filtered texture times the BRDF weight. GPU vs
+    the oracle's restatement (oracle/ggx.h), for the Lambert + Phong and the GGX model; removing the image changes it."""
+    v = np.zeros(4, dtype=api.VERTEX_DTYPE)
+    v["pos"] = [[-4, -3, 6], [4, -3, 6], [4, 3, 6], [-4, 3, 6]]
+    v["normal"] = (0, 0, -1)
+    v["uv"] = [[0, 0], [1, 0], [1, 1], [0, 1]]
+    w, h, spp = 256, 192, 8
+    for flags in (0, api.PT_MAT_GGX):
+        sc = SceneData([(v, np.array([0, 1, 2, 0, 2, 3], dtype=np.uint32))], [(0, 0, None)], [((0, 0, 0), (0.9, 0.8, 0.7, 1))])
+        sc.materials_ext = [(0.6, 0.0, 3, 3.0, flags)]
+        sc.albedo_texture = scenes.albedo_image(5, 64)
+        ctx.scene_create(sc)
+        osc = oracle.scene(sc)
+        c = lookat_consts(w, h, {"eye": (0.0, 0.0, 0.0), "target": (0.0, 0.0, 6.0)}, depth=1, sky=False)
+        for k in range(3):
+            c.mySkyFallbackEmission[k] = 1.0
+        ctx.accum_reset(w, h)
+        ctx.render(c, w, h, 0, spp)
+        img = ctx.accum_read()
+        acc, _, _ = osc.render(c, w, h, 0, spp)
+        assert rel_mse(img, acc / spp) < 1e-8, (flags, rel_mse(img, acc / spp))
+        rows = img[h // 2, :, 0]
+        assert rows.std() > 0.02 * rows.mean() > 0                    # the bricks are visible along a scan line
+        ctx.scene_set_albedo_texture(None)                           # no image: factor 1
+        ctx.accum_reset(w, h)
+        ctx.render(c, w, h, 0, spp)
+        flat = ctx.accum_read()
+        assert rel_mse(flat, acc / spp) > 1e-3 and flat[..., 0].mean() > img[..., 0].mean()
+    with pytest.raises(api.PtError):
+        ctx.scene_set_albedo_texture(np.zeros((0, 4, 4), dtype=np.uint8))
+
+
 def test_pipeline_lanes_are_bit_identical_to_single_lane(ctx, oracle):
     """PT_OPT_PIPELINE splits a batch over two streams; the halves are resolved in sample order, so the target and
     the counters must not change by a bit (odd sample counts and several batches included)."""
