@@ -197,7 +197,7 @@ def load_library():
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SYMBOLS.items():
         if os.environ.get("PT_AMD_LIB") and not hasattr(lib, name):
-            continue             # an older experiment build (tools/ab.sh) may lack newer entry points
+            continue             # an older experiment build (tools/experiments/ab.sh) may lack newer entry points
         fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol
         fn.restype = res
         fn.argtypes = args

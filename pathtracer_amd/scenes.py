@@ -25,21 +25,6 @@ def _parse_mtl(path):
     mats, cur = {}, None
     if not os.path.exists(path):
         return mats
-    def resolve(tok, count, what, lineno, required=False):
-        """1-based / negative-relative OBJ index -> 0-based, range-checked (-1 = absent)."""
-        if not tok:
-            if required:
-                raise ValueError(f"{path}:{lineno}: face corner without a position index")
-            return -1
-        try:
-            i = int(tok)
-        except ValueError:
-            raise ValueError(f"{path}:{lineno}: malformed {what} index {tok!r}") from None
-        j = i - 1 if i > 0 else count + i
-        if i == 0 or not 0 <= j < count:
-            raise ValueError(f"{path}:{lineno}: {what} index {i} out of range (have {count})")
-        return j
-
     with open(path) as f:
         for lineno, line in enumerate(f, 1):
             t = line.split()

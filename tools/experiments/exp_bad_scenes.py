@@ -1,6 +1,6 @@
 """Robustness probe: scenes with NaN / Inf / huge / degenerate vertices must not hang or crash the builder or kernels."""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from pathtracer_amd import api, scenes
 from pathtracer_amd.context import Context, SceneData

@@ -2,7 +2,7 @@
 oracle's own binary BVH (exact fp32 boxes, distance-ordered traversal) on the same incoherent rays."""
 import os, sys
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from pathtracer_amd import Context, api, scenes
 from tests import oracle_lib

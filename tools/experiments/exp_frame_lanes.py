@@ -1,5 +1,5 @@
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from pathtracer_amd import PathTracer, scenes, api
 pt = PathTracer(0, 1280, 720)
 pt.LoadScene(scenes.atrium(1), scenes.ATRIUM_CAM["eye"]); pt.myCamera.LookAt(scenes.ATRIUM_CAM["eye"], scenes.ATRIUM_CAM["target"]); pt.myLightInstanceIdx = -1

@@ -3,7 +3,7 @@ render through the host walker (tests/walker) and prints the share of node visit
 the (breadth-first) node array - the case for keeping the top of the tree somewhere closer than L1."""
 import ctypes as C, os, sys
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from pathtracer_amd import PathTracer, api, scenes
 from tests.common import lookat_consts

@@ -3,7 +3,7 @@ caches were flushed (the rays come from HBM, as in a render) and (b) after a pas
 in the Infinity Cache / L2).  usage: python tools/exp_ray_fetch_latency.py [spp]"""
 import sys, os, time
 import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from pathtracer_amd import PathTracer, api, scenes
 SPP = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 W, H = 1920, 1080

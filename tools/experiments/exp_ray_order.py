@@ -3,7 +3,7 @@ compaction leaves them), re-orders it on the host in several ways and times pt_t
 usage: python tools/exp_ray_order.py [atrium|street|street_hard|courtyard] [bounce]"""
 import sys, os, time
 import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from pathtracer_amd import PathTracer, api, scenes
 
 wl = sys.argv[1] if len(sys.argv) > 1 else "atrium"

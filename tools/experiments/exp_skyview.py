@@ -1,6 +1,6 @@
 """Diagnostic: where does the sky-view LUT (sky mode 1) differ from the marched sky?  Run on the GPU box."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from pathtracer_amd import api, scenes
 from pathtracer_amd.context import Context

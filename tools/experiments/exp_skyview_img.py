@@ -1,6 +1,6 @@
 """Diagnostic: sky mode 1 vs mode 0 images on the small atrium.  Run on the GPU box."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from pathtracer_amd import api, scenes
 from pathtracer_amd.context import Context

@@ -3,7 +3,7 @@ queue depth) on one workload. Utilisation = lanes with work per wave-step, from 
 events around the ordinary kernel. usage: python tools/exp_tri_util.py [atrium|street]"""
 import sys, os
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from pathtracer_amd import PathTracer, api, scenes
 
 wl = sys.argv[1] if len(sys.argv) > 1 else "atrium"

@@ -1,6 +1,6 @@
 """Experiment: does running two half-batches on two streams (two contexts) overlap shade with extend?"""
 import sys, os, time, json
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from pathtracer_amd import PathTracer, api, scenes
 

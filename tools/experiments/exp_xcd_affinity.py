@@ -5,7 +5,7 @@ fall into spatial cell k, and pt_trace_rays_device is timed.
 usage: PT_AMD_LIB=.../libpt_xcd.so python tools/exp_xcd_affinity.py [atrium|street] [bounce]"""
 import sys, os, time
 import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from pathtracer_amd import PathTracer, api, scenes
 
 wl = sys.argv[1] if len(sys.argv) > 1 else "atrium"

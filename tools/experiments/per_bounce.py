@@ -1,5 +1,5 @@
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from pathtracer_amd import PathTracer, api, scenes
 W, H, SPP = 1920, 1080, 4
 pt = PathTracer(0, W, H); pt.myHalfResRender = False; pt.UpdateOutputTexture()

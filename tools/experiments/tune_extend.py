@@ -1,7 +1,7 @@
 """Sweeps the extend kernel's tuning options on one workload (interleaved rounds in one process)."""
 import sys, os, itertools
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from pathtracer_amd import PathTracer, api, scenes
 
 wl = sys.argv[1] if len(sys.argv) > 1 else "atrium"

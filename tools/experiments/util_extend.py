@@ -1,6 +1,6 @@
 """Lane utilisation of the extend kernel's node and triangle phases (counting build) for a few option settings."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from pathtracer_amd import PathTracer, api, scenes
 wl = sys.argv[1] if len(sys.argv) > 1 else "atrium"
 W, H, SPP = 1920, 1080, 4
