@@ -38,10 +38,11 @@ FP32_PEAK_TFLOPS = 157.3                           # MI355X_MICROARCH.md: peak f
 L1_PEAK_GBS = 39321.6                              # vector L1 return path: 64 B/clk/CU x 256 CUs x 2.4 GHz
 PMC_ROUNDS = ("r03", "r02")                        # profiles/<round>/pmc_traffic.json, newest first
 DEF_DEFER, DEF_POSTPONE = 4, 40                    # the library defaults (csrc/kernels.h LaunchCfg)
-# k_extend's own VALU roof: most of its vector instructions (min/max, compares, selects, shifts, byte permutes, v_fma_mix)
-# issue at HALF rate on gfx950 (tools/valurate -> profiles/r02/valu_issue_rates.txt); weighted over its node and triangle
-# steps that is 3.52 cycles per wave64 instruction per SIMD (tools/valu_mix.py -> profiles/r02/valu_mix_extend.txt)
-VALU_MIX_CYCLES_EXTEND = 3.52
+# k_extend's own VALU roof: most of its vector instructions (min/max, selects, shifts, byte permutes, v_fma_mix) issue at
+# HALF rate on gfx950 (tools/valurate -> profiles/r03/valu_issue_rates.txt); weighted over its node and triangle steps that
+# is 3.41 cycles per wave64 instruction per SIMD (tools/valu_mix.py -> profiles/r03/valu_mix_extend.txt; 3.52 in round 2,
+# before the hit-mask assembly of the box test moved to full-rate forms)
+VALU_MIX_CYCLES_EXTEND = 3.41
 VALU_MIX_ROOF_GINSTR = 256 * 4 * 2.4 / VALU_MIX_CYCLES_EXTEND
 
 WORKLOADS = ("atrium", "street", "street_hard", "courtyard", "cornell")
@@ -204,7 +205,7 @@ def measure_extend(pt, ctx, api, step, W, H, SPP, depth, sample0, steps, leg):
                 "mix_cycles_per_instr": VALU_MIX_CYCLES_EXTEND, "mix_roof_ginstr_per_s": round(VALU_MIX_ROOF_GINSTR, 1),
                 "frac_of_mix_roof": round(mix, 4), "mix_roof_exceeded": bool(mix > 1.0),
                 "note": "peak = every instruction at the full rate (2 cycles per wave64 instruction per SIMD); the kernel's own mix is mostly "
-                        "half-rate instructions (profiles/r02/valu_issue_rates.txt, valu_mix_extend.txt), hence the mix roof; a value above 1 "
+                        "half-rate instructions (profiles/r03/valu_issue_rates.txt, valu_mix_extend.txt), hence the mix roof; a value above 1 "
                         "means profile and build do not belong together and is flagged, not clamped"}
     # vector-memory pipe (L1 -> VGPR return path): every wave-level load moves 64 lanes x its width whatever the lanes
     # do with it; steps of the shipped schedule (COUNT pass) x loads per step (node: 5 x 16 B, triangle: 16+12+12 B)

@@ -13,6 +13,13 @@
 #ifndef PT_BOX_AND_PERM
 #define PT_BOX_AND_PERM 1   // 1 = even plane bytes through a full-rate v_and_b32, odd ones through v_perm_b32; 0 = two byte permutes
 #endif
+#ifndef PT_BOX_SDWA_MASK
+#define PT_BOX_SDWA_MASK 1   // 1 = hit-mask assembly of the box test with SDWA byte-select shifts and a sign-of-FMA decision (see child_tests)
+#endif
+#ifndef PT_BOX_BITSEL
+#define PT_BOX_BITSEL 0   // 1 = near / far plane selection with v_bitop3_b32 bit selects (full rate) instead of v_cndmask_b32: -27 issue cycles per node step, but 3 more live registers
+                        // -> spills at the pinned 6 waves per SIMD: C2 extend -1 %, C5 +-0 (profiles/r03/ab_box_mask_bitsel.txt); off
+#endif
 #ifndef PT_NODE_STRIDE_U4
 #define PT_NODE_STRIDE_U4 5   // device stride of a BVH node in 16-byte units (5 = packed 80-byte nodes)
 #endif
@@ -190,9 +197,25 @@ struct Traverser {
       const uint32_t meta4 = h ? n1.w : n1.z;
       const uint32_t qlx = h ? n2.y : n2.x, qly = h ? n2.w : n2.z, qlz = h ? n3.y : n3.x;
       const uint32_t qhx = h ? n3.w : n3.z, qhy = h ? n4.y : n4.x, qhz = h ? n4.w : n4.z;
+#if PT_BOX_BITSEL
+      // near / far plane dwords by direction sign as full-rate bit selects against an all-ones / all-zeros mask (the sign of
+      // the reciprocal direction spread over the word) instead of half-rate v_cndmask_b32; pinned as asm, the compiler turns
+      // the C form back into compare + select
+      uint32_t mx, my, mz, nx, fx, ny, fy, nz, fz;
+      asm("v_ashrrev_i32_e32 %0, 31, %1" : "=v"(mx) : "v"(idx));
+      asm("v_ashrrev_i32_e32 %0, 31, %1" : "=v"(my) : "v"(idy));
+      asm("v_ashrrev_i32_e32 %0, 31, %1" : "=v"(mz) : "v"(idz));
+#define PT_BITSEL(dst, a, b, m) asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0xe4" : "=v"(dst) : "v"(a), "v"(b), "v"(m))   /* m ? a : b, bitwise */
+      PT_BITSEL(nx, qhx, qlx, mx); PT_BITSEL(fx, qlx, qhx, mx);
+      PT_BITSEL(ny, qhy, qly, my); PT_BITSEL(fy, qly, qhy, my);
+      PT_BITSEL(nz, qhz, qlz, mz); PT_BITSEL(fz, qlz, qhz, mz);
+#undef PT_BITSEL
+      (void)negx; (void)negy; (void)negz;
+#else
       const uint32_t nx = negx ? qhx : qlx, fx = negx ? qlx : qhx;
       const uint32_t ny = negy ? qhy : qly, fy = negy ? qly : qhy;
       const uint32_t nz = negz ? qhz : qlz, fz = negz ? qlz : qhz;
+#endif
       const uint32_t is_inner4 = (meta4 & (meta4 << 1)) & 0x10101010u;
       // 0b111 in every byte of an internal child (only the three octant bits are ever masked). Two shift-or instructions,
       // pinned as asm: the compiler folds every C form of this back into a quarter-rate v_mul_lo_u32.
@@ -250,11 +273,33 @@ struct Traverser {
         const float tn = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, ray.tmin));
         const float tf = fminf(fminf(tfx, tfy), fminf(tfz, best.t));
         // conservative: widen by ~8 ulp so fp32 rounding of the slab arithmetic can never cull a true hit
+#if PT_BOX_SDWA_MASK
+        // Mask assembly at issue cost (tools/valurate: shifts, bit-field extracts, compares and selects are half-rate; FMA
+        // and the bit-logic forms full-rate). (1) The child's mask bits cb << bi with ONE sub-dword-addressed shift that
+        // reads byte j of both packed registers, instead of two byte extractions and a shift. (2) The decision
+        // tn <= tf * 1.000001 as the sign of ONE fused multiply-add tf * 1.000001 - tn (exact sign of the real difference:
+        // +0 on equality, a hit; tn and tf are never NaN, fmaxf / fminf against the finite tmin / best.t drop them),
+        // spread over the word by an arithmetic shift and applied with and-not + or, instead of multiply, compare,
+        // select and or. The compare now sees the exact product rather than the rounded one: half an ulp of the 8-ulp
+        // margin, and tests/walker mirrors it so the visit counts stay equal to the kernel's.
+        uint32_t m;
+        switch (j) {
+          case 0: asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:BYTE_0" : "=v"(m) : "v"(bit_index4), "v"(child_bits4)); break;
+          case 1: asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:BYTE_1" : "=v"(m) : "v"(bit_index4), "v"(child_bits4)); break;
+          case 2: asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:BYTE_2" : "=v"(m) : "v"(bit_index4), "v"(child_bits4)); break;
+          default: asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:BYTE_3" : "=v"(m) : "v"(bit_index4), "v"(child_bits4)); break;
+        }
+        const float dlt = __builtin_fmaf(tf, 1.000001f, -tn);
+        uint32_t miss;   // all ones: the interval is empty. Both pinned as asm: the compiler rewrites the C forms into compare + select
+        asm("v_ashrrev_i32_e32 %0, 31, %1" : "=v"(miss) : "v"(dlt));
+        asm("v_bitop3_b32 %0, %1, %2, %0 bitop3:0xba" : "+v"(hitmask) : "v"(m), "v"(miss));   // hitmask | (m & ~miss)
+#else
         if (tn <= tf * 1.000001f) {
           const uint32_t cb = (child_bits4 >> (8 * j)) & 0xffu;
           const uint32_t bi = (bit_index4 >> (8 * j)) & 0xffu;
           hitmask |= cb << bi;
         }
+#endif
       }
     }
   }

@@ -135,7 +135,8 @@ extern "C" int bvh8_walk(const PtBvh8Node* nodes, uint64_t num_nodes, const void
           }
           tn = std::fmax(std::fmax(tnear[0], tnear[1]), std::fmax(tnear[2], r.tmin));
           tf = std::fmin(std::fmin(tfar[0], tfar[1]), std::fmin(tfar[2], best.t));
-          if (!(tn <= tf * 1.000001f)) continue;
+          // the kernel's decision (traverse_device.h, PT_BOX_SDWA_MASK): the sign of ONE fused tf * 1.000001 - tn
+          if (std::signbit(std::fmaf(tf, 1.000001f, -tn))) continue;
           const bool inner = (meta & 0x18u) == 0x18u;          // low five bits 0b11sss: only internal children reach 24+
           const uint32_t bits = meta >> 5;                       // internal: 1; leaf: triangle count in unary
           const uint32_t pos = inner ? 24u + (((uint32_t)meta & 7u) ^ oct) : ((uint32_t)meta & 0x1fu);
