@@ -1,6 +1,6 @@
 """Triangle-phase lane utilisation against extend rate: sweeps the deferred schedule's thresholds (postpone %, continue %,
 queue depth) on one workload. Utilisation = lanes with work per wave-step, from the COUNT instantiation; rate from HIP
-events around the ordinary kernel. usage: python tools/exp_tri_util.py [atrium|street]"""
+events around the ordinary kernel. usage: python tools/experiments/exp_tri_util.py [atrium|street|street_hard|courtyard] [postpone,continue,queue,lds_stack ...]"""
 import sys, os
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
@@ -8,17 +8,22 @@ from pathtracer_amd import PathTracer, api, scenes
 
 wl = sys.argv[1] if len(sys.argv) > 1 else "atrium"
 W, H, SPP = 1920, 1080, 8
-scene, cam, depth = {"atrium": (scenes.atrium, scenes.ATRIUM_CAM, 4), "street": (scenes.street, scenes.STREET_CAM, 8)}[wl]
+scene, cam, depth = {"atrium": (scenes.atrium, scenes.ATRIUM_CAM, 4), "street": (scenes.street, scenes.STREET_CAM, 8),
+                     "street_hard": (scenes.street_hard, scenes.STREET_HARD_CAM, 8), "courtyard": (scenes.courtyard, scenes.COURTYARD_CAM, 16)}[wl]
 pt = PathTracer(0, W, H); pt.myHalfResRender = False; pt.UpdateOutputTexture()
 pt.LoadScene(scene(), cam["eye"]); pt.myCamera.LookAt(cam["eye"], cam["target"])
 pt.mySampleSky = True; pt.myLightInstanceIdx = -1; pt.myMaxRecursionDepth = depth
 pt.mySky.ComputeTranmittanceLut(); pt._sky_dirty = False
 c = pt.BuildRtConsts(); ctx = pt.ctx
 ctx.set_option(api.PT_OPT_SAMPLES_PER_BATCH, SPP)
-grid = [(50, 25, 4), (50, 50, 4), (75, 50, 4), (75, 75, 4), (90, 75, 4), (50, 25, 6), (75, 75, 6), (90, 90, 6), (25, 10, 4), (0, 0, 4)]
+grid = [(40, 25, 4, 6), (50, 25, 4, 6), (50, 50, 4, 6), (75, 50, 4, 6), (40, 25, 6, 6), (40, 25, 6, 4), (40, 25, 8, 4), (40, 25, 8, 6), (60, 40, 8, 4), (60, 40, 6, 4),
+        (40, 25, 12, 6), (25, 10, 4, 6), (40, 25, 2, 6)]
+if len(sys.argv) > 2:
+    grid = [tuple(int(x) for x in g.split(",")) for g in sys.argv[2:]]
 rows = []
-for (post, cont, defer) in grid:
+for (post, cont, defer, lds_stack) in grid:
     ctx.set_tuning(api.PT_TUNE_EXTEND_POSTPONE_PCT, post); ctx.set_tuning(api.PT_TUNE_EXTEND_CONTINUE_PCT, cont); ctx.set_tuning(api.PT_TUNE_EXTEND_DEFER, defer)
+    ctx.set_tuning(api.PT_TUNE_EXTEND_LDS_STACK, lds_stack)
     ctx.set_option(api.PT_OPT_COUNT_TRAVERSAL, 1); ctx.stats_reset()
     ctx.render(c, W, H, 0, SPP)
     s = ctx.stats()
@@ -32,4 +37,4 @@ for (post, cont, defer) in grid:
         rates.append(t.rays / t.extend_ms / 1e3)
     ctx.set_option(api.PT_OPT_TIME_KERNELS, 0)
     rows.append((post, cont, defer, nu, tu, npr, tpr, float(np.median(rates))))
-    print(f"postpone {post:3d}%  continue {cont:3d}%  queue {defer}:  node-phase util {nu:.3f}  tri-phase util {tu:.3f}  nodes/ray {npr:6.2f}  tris/ray {tpr:5.2f}  extend {np.median(rates):8.1f} Mrays/s", flush=True)
+    print(f"postpone {post:3d}%  continue {cont:3d}%  queue {defer:2d}  lds stack {lds_stack}:  node-phase util {nu:.3f}  tri-phase util {tu:.3f}  nodes/ray {npr:6.2f}  tris/ray {tpr:5.2f}  extend {np.median(rates):8.1f} Mrays/s", flush=True)
