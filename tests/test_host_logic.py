@@ -413,3 +413,40 @@ def test_bvh8_builder_both_leaf_formats_walk_to_the_oracle_hits(oracle, scene):
         assert stats[1][2] > 0.45 * len(tris) and stats[1][0] < 0.8 * stats[0][0]     # quads pair up; fewer nodes
     else:
         assert 1 <= stats[1][2] <= 8                              # a random soup shares no edges; the duplicates do
+
+
+def test_roofline_pmc_entry_is_tied_to_the_build(tmp_path, monkeypatch):
+    """bench.py prices k_extend's launch time against committed PMC counters only when they were measured on THIS build of
+    the kernels: every entry of profiles/<round>/pmc_traffic.json carries the fingerprint of the sources it ran on."""
+    import json
+    import bench
+    fp = bench.build_fingerprint()
+    assert len(fp) == 16 and fp == bench.build_fingerprint()
+    # the committed round-3 entry of the driver's default command belongs to the build in the tree
+    entry, stale = bench.find_pmc("atrium", 1920, 1080, 64, 4, 0, 0, fp)
+    assert entry is not None and entry["round"] == "r03"
+    assert not stale, "profiles/r03/pmc_traffic.json was measured on another build: run tools/run_final_refresh.sh r03"
+    entry, stale = bench.find_pmc("atrium", 1920, 1080, 64, 4, 0, 0, "0" * 16)
+    assert entry is not None and stale
+    assert bench.find_pmc("atrium", 1921, 1080, 64, 4, 0, 0, fp) == (None, False)     # another size: no entry at all
+    # a changed source changes the fingerprint
+    root = tmp_path / "r"
+    (root / "pathtracer_amd" / "csrc").mkdir(parents=True)
+    (root / "include").mkdir()
+    (root / "pathtracer_amd" / "csrc" / "kernels.hip").write_text("a")
+    (root / "include" / "pt_api.h").write_text("b")
+    monkeypatch.setattr(bench, "ROOT", str(root))
+    f1 = bench.build_fingerprint()
+    (root / "pathtracer_amd" / "csrc" / "kernels.hip").write_text("a ")
+    f2 = bench.build_fingerprint()
+    assert f1 != f2
+    # entries without a fingerprint (round 2's) are always stale; newest round wins
+    (root / "profiles" / "r02").mkdir(parents=True)
+    e = {"workload": "atrium", "width": 8, "height": 8, "spp_per_step": 1, "depth": 4}
+    (root / "profiles" / "r02" / "pmc_traffic.json").write_text(json.dumps([e]))
+    entry, stale = bench.find_pmc("atrium", 8, 8, 1, 4, 0, 0, f2)
+    assert entry["round"] == "r02" and stale
+    (root / "profiles" / "r03").mkdir()
+    (root / "profiles" / "r03" / "pmc_traffic.json").write_text(json.dumps([dict(e, build_fingerprint=f2)]))
+    entry, stale = bench.find_pmc("atrium", 8, 8, 1, 4, 0, 0, f2)
+    assert entry["round"] == "r03" and not stale
