@@ -104,8 +104,9 @@ def load_workload(pt, name, depth=-1, material_ext=0):
     return scene, d, label
 
 
-def find_pmc(workload, W, H, SPP, depth, material_ext, russian_roulette, fingerprint):
-    """The committed PMC entry of this exact workload; (entry, stale). stale = measured on another build of the kernels."""
+def find_pmc(workload, W, H, SPP, depth, material_ext, russian_roulette, fingerprint, shared_phase=0):
+    """The committed PMC entry of this exact workload and triangle-phase variant; (entry, stale). stale = measured on another
+    build of the kernels."""
     for rnd in PMC_ROUNDS:
         try:
             with open(os.path.join(ROOT, "profiles", rnd, "pmc_traffic.json")) as f:
@@ -115,7 +116,8 @@ def find_pmc(workload, W, H, SPP, depth, material_ext, russian_roulette, fingerp
         for e in entries:
             try:
                 if (e["workload"], e["width"], e["height"], e["spp_per_step"], e["depth"]) == (workload, W, H, SPP, depth) \
-                        and (e.get("material_ext", 0), e.get("russian_roulette", 0)) == (material_ext, russian_roulette):
+                        and (e.get("material_ext", 0), e.get("russian_roulette", 0), e.get("shared_triangle_phase", 0)) == \
+                        (material_ext, russian_roulette, shared_phase):
                     return dict(e, round=rnd), e.get("build_fingerprint") != fingerprint
             except KeyError:
                 continue
@@ -172,7 +174,8 @@ def measure_extend(pt, ctx, api, step, W, H, SPP, depth, sample0, steps, leg):
     #     tools/prof_pmc.sh -> tools/pmc_traffic.py -> profiles/<round>/pmc_traffic.json, matched on workload, size, batch,
     #     depth AND the fingerprint of the kernel sources): VALU wave-instructions and fabric-side bytes per extend launch.
     fp = build_fingerprint()
-    pmc, stale = find_pmc(leg["workload"], W, H, SPP, depth, leg.get("material_ext", 0), leg.get("russian_roulette", 0), fp)
+    shared_used = 1 if se.shared_launches > 0 else 0
+    pmc, stale = find_pmc(leg["workload"], W, H, SPP, depth, leg.get("material_ext", 0), leg.get("russian_roulette", 0), fp, shared_used)
     pmc_round = pmc["round"] if pmc else None
     if stale:
         pmc = None   # counters of another build are never paired with this build's launch times
@@ -251,6 +254,10 @@ def measure_extend(pt, ctx, api, step, W, H, SPP, depth, sample0, steps, leg):
                            if packet else None),
         "primary_kernel_choice": {"option": leg.get("primary_packet", 2), "timed_ms_k_extend": round(se.packet_cal_ms[0], 4),
                                   "timed_ms_k_extend_packet": round(se.packet_cal_ms[1], 4)},
+        "triangle_phase": {"option": leg.get("shared_triangle_phase", 2), "choice": int(se.shared_choice), "shared_used": shared_used,
+                           "timed_ms_per_lane": round(se.shared_cal_ms[0], 4), "timed_ms_shared": round(se.shared_cal_ms[1], 4),
+                           "note": "PT_OPT_SHARED_TRIANGLE_PHASE: the wave pools its rays' pending leaf records and tests them 64 at a time; "
+                                   "option 2 times both forms on the warm-up step's bounce-1 queue and keeps the shared one if it wins by 3 %"},
         "bytes_per_launch": round(alg_bytes, 1),
         "extend_share_of_render": round(se.extend_ms / max(se.render_ms, 1e-9), 4),
         "extend_mrays_per_s": round(se.rays / max(ext_s, 1e-12) / 1e6, 2),
@@ -272,6 +279,7 @@ def run_config_leg(pt, ctx, api, ptdist, dev, spec):
     consts = pt.BuildRtConsts()
     ctx.set_option(api.PT_OPT_SAMPLES_PER_BATCH, SPP)
     ctx.set_option(api.PT_OPT_RUSSIAN_ROULETTE, spec.get("russian_roulette", 0))
+    ctx.set_option(api.PT_OPT_SHARED_TRIANGLE_PHASE, spec.get("shared_triangle_phase", 2))
 
     def step(first):
         ctx.render(consts, W, H, first, SPP)
@@ -300,7 +308,7 @@ def run_config_leg(pt, ctx, api, ptdist, dev, spec):
         "triangles": int(info.num_triangles), "bvh_nodes": int(info.num_bvh_nodes), "bvh_mb": round(info.bvh_bytes / 1e6, 2),
         "bvh_build_ms": round(info.build_ms, 1),
         "roofline": {k: roof[k] for k in ("bound", "achieved", "peak", "unit", "frac", "frac_algorithmic", "pmc_stale", "traffic", "avg_launch_ms",
-                                          "launches", "shipped_schedule", "primary_kernel")},
+                                          "launches", "shipped_schedule", "primary_kernel", "triangle_phase")},
         "hbm_algorithmic_ratio": roof["hbm_algorithmic"]["ratio_to_hbm_peak"],
         "leg_wall_s": round(time.perf_counter() - t_leg, 1),
     }
@@ -337,6 +345,9 @@ def main():
     ap.add_argument("--primary-packet", type=int, default=2, choices=[0, 1, 2],
                     help="PT_OPT_PRIMARY_PACKET: 0 = the primaries are traced by k_extend, 1 = by k_extend_packet, 2 (library default) = "
                          "by whichever the library times faster on this scene and frame size")
+    ap.add_argument("--shared-triangle-phase", type=int, default=2, choices=[0, 1, 2],
+                    help="PT_OPT_SHARED_TRIANGLE_PHASE: 0 = every lane tests its own ray's leaf records, 1 = the wave pools them, 2 (library "
+                         "default) = whichever the library times faster on this scene (during the warm-up step)")
     ap.add_argument("--total-spp", type=int, default=0,
                     help="N > 1, strong scaling: samples per pixel of the whole job, partitioned over the ranks (default: steps x "
                          "spp-per-step; BASELINE C3 is 4096)")
@@ -404,6 +415,8 @@ def main():
     ctx.set_option(api.PT_OPT_PIPELINE, args.pipeline)
     ctx.set_option(api.PT_OPT_RUSSIAN_ROULETTE, args.russian_roulette)
     ctx.set_option(api.PT_OPT_PRIMARY_PACKET, args.primary_packet)
+    if args.shared_triangle_phase != 2 or not os.environ.get("PT_AMD_LIB"):   # (an experiment library may predate the option)
+        ctx.set_option(api.PT_OPT_SHARED_TRIANGLE_PHASE, args.shared_triangle_phase)
 
     # ---- which samples this rank renders in the timed region ----
     strong = world > 1 and not args.weak
@@ -478,7 +491,7 @@ def main():
     rays_all, samples_all = float(counts[0].item()), float(counts[1].item())
 
     leg = {"workload": args.workload, "material_ext": args.material_ext, "russian_roulette": args.russian_roulette,
-           "primary_packet": args.primary_packet}
+           "primary_packet": args.primary_packet, "shared_triangle_phase": args.shared_triangle_phase}
     roofline = None
     if rank == 0 and not args.no_roofline:
         if args.bit_identical:
@@ -528,7 +541,8 @@ def main():
             if key not in want:
                 continue
             try:
-                configs[key] = run_config_leg(pt, ctx, api, ptdist, dev, dict(spec, primary_packet=args.primary_packet))
+                configs[key] = run_config_leg(pt, ctx, api, ptdist, dev, dict(spec, primary_packet=args.primary_packet,
+                                                                              shared_triangle_phase=args.shared_triangle_phase))
             except Exception as e:   # a failed leg must not take the headline down with it; it is reported as failed
                 configs[key] = {"error": f"{type(e).__name__}: {e}"}
 

@@ -181,6 +181,10 @@ typedef struct PtStats {
   uint64_t extend_launches_bounce[16]; /* traversal-kernel launches at bounce b */
   uint64_t packet_launches;      /* of those, launches of k_extend_packet (the coherent-primaries kernel, PT_OPT_PRIMARY_PACKET) */
   float packet_cal_ms[2];        /* PT_OPT_PRIMARY_PACKET = 2: what the one-off timing measured on <= 2^24 primaries: k_extend, k_extend_packet */
+  uint64_t shared_launches;      /* traversal-kernel launches that ran the shared triangle phase (PT_OPT_SHARED_TRIANGLE_PHASE) */
+  float shared_cal_ms[2];        /* PT_OPT_SHARED_TRIANGLE_PHASE = 2: what the one-off timing measured on a bounce-1 queue: per-lane, shared */
+  int32_t shared_choice;         /* its outcome: -1 = not timed yet (per-lane until then), 0 = per-lane, 1 = shared */
+  uint32_t reserved1;
 } PtStats;
 
 typedef struct PtSceneInfo {
@@ -219,11 +223,18 @@ enum {
                                       streams with their own wavefront state, so consecutive calls overlap on the GPU; their resolves stay
                                       on the ctx stream in call order, so the target is bit-identical to 1 (= every call serial on the ctx
                                       stream). Each lane in use holds its own queues and ~150 MB of traversal-stack spill region. */
-  PT_OPT_PRIMARY_PACKET = 15       /* which kernel traces the fused primaries of pt_render (coherent 8x8-pixel tiles): 0 = the general per-lane
+  PT_OPT_PRIMARY_PACKET = 15,      /* which kernel traces the fused primaries of pt_render (coherent 8x8-pixel tiles): 0 = the general per-lane
                                       traversal, 1 = one BVH walk per wave with wave-uniform node fetches (k_extend_packet), 2 (default) = the
                                       faster of the two, timed once per scene and frame size on <= 2^24 primaries. That FIRST pt_render call
                                       per scene and frame size blocks the host (one stream synchronisation) and cannot be stream-captured;
                                       callers that need every call asynchronous set 0 or 1. Same hit records either way. */
+  PT_OPT_SHARED_TRIANGLE_PHASE = 17 /* how the traversal kernel runs its triangle tests: 0 = every lane tests the records of its own ray, 1 = the
+                                      wave pools the pending records of its 64 rays and tests them 64 at a time, whoever owns them (a hit goes
+                                      back to its ray through an LDS minimum on (t, triangle id), so the closest hit and its tie-break are the
+                                      same), 2 (default) = the faster of the two for this scene: the first pt_render batch of >= 2^21 paths
+                                      traces its bounce-1 queue twice more under HIP events and a later call reads them; nothing blocks, and
+                                      until then the per-lane form runs. Pays where leaves are big and uneven (long thin triangles, spatial
+                                      splits: +8 % on the SAH-hostile street), costs ~1 % on regular scenes. Same hit records either way. */
 };
 
 /* ---- lifetime (replaces the RenderCore device + handle ownership, PathTracer.cpp:45-77,417-437) ---- */

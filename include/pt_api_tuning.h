@@ -20,7 +20,13 @@ enum {
   PT_TUNE_EXTEND_LDS_STACK = 8,     /* per-lane traversal-stack entries kept in LDS, the rest spills to HBM (6) */
   PT_TUNE_EXTEND_DEFER = 9,         /* 0 = postpone triangle groups on the stack; N > 0 = park up to N groups per lane (4) */
   PT_TUNE_EXTEND_TOP_NODES = 12,    /* BVH nodes (breadth-first order: the top of the tree) every traversal block keeps in LDS (73) */
-  PT_TUNE_EXTEND_CONTINUE_PCT = 13  /* a triangle phase goes on while >= this % of the busy lanes have work (25) */
+  PT_TUNE_EXTEND_CONTINUE_PCT = 13, /* a triangle phase goes on while >= this % of the busy lanes have work (25) */
+  /* the same four for launches that run the shared triangle phase (PT_OPT_SHARED_TRIANGLE_PHASE), which has its own schedule:
+     its 2 KB of LDS per wave come out of the parked-group queue and the top-node cache */
+  PT_TUNE_SHARED_DEFER = 18,        /* parked groups per lane, 1..16 (3) */
+  PT_TUNE_SHARED_TOP_NODES = 19,    /* (8) */
+  PT_TUNE_SHARED_POSTPONE_PCT = 20, /* (25) */
+  PT_TUNE_SHARED_CONTINUE_PCT = 21  /* a pass of fewer records than this % of the busy lanes is left for a fuller one (50) */
 };
 
 /* Sets one knob on this ctx (PT_ERR_INVALID_ARG outside its range). pt_set_option rejects these ids. */

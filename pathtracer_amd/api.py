@@ -39,6 +39,7 @@ PT_OPT_PIPELINE = 11
 PT_OPT_FUSED_PRIMARY = 14
 PT_OPT_PRIMARY_PACKET = 15
 PT_OPT_FRAME_LANES = 16
+PT_OPT_SHARED_TRIANGLE_PHASE = 17
 
 # include/pt_api_tuning.h: schedule knobs of the traversal kernel, set through pt_debug_set_tuning (tools and tests only)
 PT_TUNE_EXTEND_FETCH_MIN = 5
@@ -48,6 +49,10 @@ PT_TUNE_EXTEND_LDS_STACK = 8
 PT_TUNE_EXTEND_DEFER = 9
 PT_TUNE_EXTEND_TOP_NODES = 12
 PT_TUNE_EXTEND_CONTINUE_PCT = 13
+PT_TUNE_SHARED_DEFER = 18
+PT_TUNE_SHARED_TOP_NODES = 19
+PT_TUNE_SHARED_POSTPONE_PCT = 20
+PT_TUNE_SHARED_CONTINUE_PCT = 21
 
 (PT_FN_RAND01, PT_FN_FRESNEL, PT_FN_SPEC_PROB, PT_FN_SAMPLE_PHONG, PT_FN_EVAL_PHONG, PT_FN_COS_HEMISPHERE,
  PT_FN_LAMBERT, PT_FN_SKY, PT_FN_PRIMARY_RAY, PT_FN_SKY_VIEW_LUT, PT_FN_GGX_SAMPLE, PT_FN_ALBEDO_PATTERN) = range(12)
@@ -127,7 +132,8 @@ class PtStats(C.Structure):   # versioned by size: struct_size is set by the cal
                 ("extend_ms", C.c_double), ("render_ms", C.c_double),
                 ("rays_bounce", C.c_uint64 * 16), ("extend_ms_bounce", C.c_double * 16),
                 ("node_wave_steps", C.c_uint64), ("tri_wave_steps", C.c_uint64),
-                ("extend_launches_bounce", C.c_uint64 * 16), ("packet_launches", C.c_uint64), ("packet_cal_ms", C.c_float * 2)]
+                ("extend_launches_bounce", C.c_uint64 * 16), ("packet_launches", C.c_uint64), ("packet_cal_ms", C.c_float * 2),
+                ("shared_launches", C.c_uint64), ("shared_cal_ms", C.c_float * 2), ("shared_choice", C.c_int32), ("reserved1", C.c_uint32)]
 
 
 class PtSceneInfo(C.Structure):

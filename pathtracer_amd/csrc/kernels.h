@@ -83,6 +83,9 @@ struct LaunchCfg {
   uint32_t defer_entries = 4;     // >0: deferred-triangle schedule with this many parked groups per lane
   bool no_private_segment = false; // launch the extend instantiation that uses no scratch memory (pt_trace_rays_device_noalloc)
   uint32_t top_nodes = 73;        // nodes of the tree's top (breadth-first order: 1 + 8 + 64) kept in LDS by every extend block
+  // shared triangle phase (k_extend<.., SHARED = true>): its own schedule, tuned with it (tools/experiments/run_shared_tri.sh)
+  bool shared_tri = false;
+  uint32_t sh_defer_entries = 3, sh_top_nodes = 8, sh_postpone_pct = 25, sh_continue_pct = 50;
 };
 
 void launch_transmittance_lut(const PtAtmosphere& atm, uint2* lut, hipStream_t s);
@@ -112,7 +115,7 @@ void launch_debug_eval(int fn, const PtRtConsts& c, const uint2* lut, const floa
 void launch_extend_packet(const DeviceScene& sc, const float4* ray_o, const float4* ray_d, float4* hits, const uint32_t* count,
                           uint32_t* work_cursor, int blocks, hipStream_t s, const float4* primary_gen);
 int extend_packet_occupancy_blocks(uint32_t stack_entries, bool paired);
-size_t extend_lds_bytes(uint32_t lds_entries_total, uint32_t top_nodes);
+size_t extend_lds_bytes(uint32_t lds_entries_total, uint32_t top_nodes, bool shared = false);
 int extend_ns_private_bytes(bool defer, bool paired, size_t* bytes_out);   // 0 = ok; private-segment bytes of the k_extend_ns instantiation
 int extend_occupancy_blocks(uint32_t lds_entries_total, uint32_t top_nodes, bool defer, bool paired, bool no_private_segment = false);
 

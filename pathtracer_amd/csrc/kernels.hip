@@ -187,6 +187,16 @@ __global__ void k_primary_setup(PtRtConsts c, float4* __restrict__ gen, uint32_t
 // stack while fewer than postpone_pct % of the busy lanes have any. Either way the wave spends its instructions on box
 // tests or on triangle tests with most lanes active.
 
+// SHARED (deferred schedule only): the triangle phase pools the pending records of all 64 lanes and tests them 64 at a
+// time, whoever owns them (extend_kernel.inc). It pays on scenes whose leaves are big and uneven (street_hard: triangle
+// phase at 0.30 lane utilisation -> 0.72, extend +8 %) and costs about 1 % elsewhere (its LDS comes out of the top-node
+// cache and the parked-group queue), so pt_api.cpp picks per scene by timing both once (PT_OPT_SHARED_TRIANGLE_PHASE).
+#ifndef PT_SHARED_LIST
+#define PT_SHARED_LIST 256u  // records per pass of a shared triangle phase (4 bytes of LDS each, per wave)
+#endif
+#ifndef PT_SHARED_TAKE
+#define PT_SHARED_TAKE 4u    // records a lane offers per pass (64 x PT_SHARED_TAKE <= PT_SHARED_LIST)
+#endif
 #ifndef PT_EXTEND_NODE_STEPS
 #define PT_EXTEND_NODE_STEPS 3   // box tests per scheduler iteration of the deferred schedule (1..4; C2 extend: 6.79, 6.95, 6.98, 6.83 Grays/s)
 #endif
@@ -939,25 +949,26 @@ void launch_primary_setup(const PtRtConsts& c, const WavefrontBuffers& wb, uint3
   hipLaunchKernelGGL(k_primary_setup, dim3(1), dim3(64), 0, s, c, wb.gen, wb.counters, w, h, first_sample, w * h * samples_in_batch);
 }
 
-size_t extend_lds_bytes(uint32_t lds_entries_total, uint32_t top_nodes) {
-  return (size_t)lds_entries_total * 64u * sizeof(uint2) * 4u + (size_t)top_nodes * PT_NODE_STRIDE_U4 * 16u;
+size_t extend_lds_bytes(uint32_t lds_entries_total, uint32_t top_nodes, bool shared) {
+  return (size_t)lds_entries_total * 64u * sizeof(uint2) * 4u + (size_t)top_nodes * PT_NODE_STRIDE_U4 * 16u +
+         (shared ? 4u * (1024u + PT_SHARED_LIST * 4u) : 0u);   // per wave: 64 hit keys, 64 (u, v) pairs, the record list of a shared triangle phase
 }
 
 int extend_occupancy_blocks(uint32_t lds_entries_total, uint32_t top_nodes, bool defer, bool paired, bool no_private_segment) {
   int nb = 0;
-  const size_t lds = extend_lds_bytes(lds_entries_total, top_nodes);
+  const size_t lds = extend_lds_bytes(lds_entries_total, top_nodes, false);
   if (no_private_segment) {
-    const hipError_t e = paired ? (defer ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_extend_ns<false, true, true>, 256, lds)
-                                         : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_extend_ns<false, false, true>, 256, lds))
-                                : (defer ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_extend_ns<false, true, false>, 256, lds)
-                                         : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_extend_ns<false, false, false>, 256, lds));
+    const hipError_t e = paired ? (defer ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_extend_ns<false, true, true, false>, 256, lds)
+                                         : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_extend_ns<false, false, true, false>, 256, lds))
+                                : (defer ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_extend_ns<false, true, false, false>, 256, lds)
+                                         : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_extend_ns<false, false, false, false>, 256, lds));
     return (e != hipSuccess || nb < 1) ? 1 : nb;
   }
   // per instantiation: the pair test holds one more vertex in registers (5 waves per SIMD instead of 6)
-  const hipError_t e = paired ? (defer ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_extend<false, true, true>, 256, lds)
-                                       : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_extend<false, false, true>, 256, lds))
-                              : (defer ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_extend<false, true, false>, 256, lds)
-                                       : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_extend<false, false, false>, 256, lds));
+  const hipError_t e = paired ? (defer ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_extend<false, true, true, false>, 256, lds)
+                                       : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_extend<false, false, true, false>, 256, lds))
+                              : (defer ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_extend<false, true, false, false>, 256, lds)
+                                       : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_extend<false, false, false, false>, 256, lds));
   if (e != hipSuccess || nb < 1) nb = 1;
   return nb;
 }
@@ -965,42 +976,50 @@ int extend_occupancy_blocks(uint32_t lds_entries_total, uint32_t top_nodes, bool
 void launch_extend(const DeviceScene& sc, const float4* ray_o, const float4* ray_d, uint32_t stride, float4* hits, const uint32_t* count,
                    uint32_t* work_cursor, unsigned long long* stats, bool count_traversal, bool any_hit, const LaunchCfg& cfg, hipStream_t s,
                    const float4* primary_gen) {
+  // the shared triangle phase exists in the deferred schedule's ordinary instantiations only; its LDS (2 KB per wave) comes
+  // out of the parked-group queue and the top-node cache, so that as many blocks stay resident as without it
+  const bool shared = cfg.shared_tri && cfg.defer_entries > 0 && !cfg.no_private_segment;
+  const uint32_t dq = shared ? cfg.sh_defer_entries : cfg.defer_entries;
+  const uint32_t postpone_pct = shared ? cfg.sh_postpone_pct : cfg.postpone_pct, continue_pct = shared ? cfg.sh_continue_pct : cfg.continue_pct;
   uint32_t lds_entries = sc.stack_entries < cfg.lds_stack_entries ? sc.stack_entries : cfg.lds_stack_entries;
-  if (lds_entries + cfg.defer_entries > PT_EXTEND_MAX_LDS_ENTRIES)   // 2 KB of LDS per entry and block: stay within one CU's LDS
-    lds_entries = PT_EXTEND_MAX_LDS_ENTRIES - cfg.defer_entries;     // the rest of the stack goes to the spill region
+  if (lds_entries + dq > PT_EXTEND_MAX_LDS_ENTRIES)   // 2 KB of LDS per entry and block: stay within one CU's LDS
+    lds_entries = PT_EXTEND_MAX_LDS_ENTRIES - dq;     // the rest of the stack goes to the spill region
   const uint32_t spill_entries = sc.stack_entries - lds_entries;
-  const uint32_t dq = cfg.defer_entries;
-  uint32_t top_nodes = sc.num_nodes < cfg.top_nodes ? sc.num_nodes : cfg.top_nodes;
-  while (top_nodes > 0 && extend_lds_bytes(lds_entries + dq, top_nodes) > 160u * 1024u) top_nodes /= 2;   // one CU's LDS
-  const size_t lds = extend_lds_bytes(lds_entries + dq, top_nodes);
+  const uint32_t want_top = shared ? cfg.sh_top_nodes : cfg.top_nodes;
+  uint32_t top_nodes = sc.num_nodes < want_top ? sc.num_nodes : want_top;
+  while (top_nodes > 0 && extend_lds_bytes(lds_entries + dq, top_nodes, shared) > 160u * 1024u) top_nodes /= 2;   // one CU's LDS
+  const size_t lds = extend_lds_bytes(lds_entries + dq, top_nodes, shared);
   if (lds > 64 * 1024) {   // deep BVHs: opt in to more than the default dynamic-LDS limit. The attribute belongs to the CURRENT
                            // device (one process may drive several, pt_reduce), so it is set on every such launch: no cached flag.
-#define PT_EXTEND_ATTR(C, D, P) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_extend<C, D, P>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
-    PT_EXTEND_ATTR(false, false, false); PT_EXTEND_ATTR(true, false, false); PT_EXTEND_ATTR(false, true, false); PT_EXTEND_ATTR(true, true, false);
-    PT_EXTEND_ATTR(false, false, true); PT_EXTEND_ATTR(true, false, true); PT_EXTEND_ATTR(false, true, true); PT_EXTEND_ATTR(true, true, true);
+#define PT_EXTEND_ATTR(C, D, P, S) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_extend<C, D, P, S>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
+    PT_EXTEND_ATTR(false, false, false, false); PT_EXTEND_ATTR(true, false, false, false); PT_EXTEND_ATTR(false, true, false, false); PT_EXTEND_ATTR(true, true, false, false);
+    PT_EXTEND_ATTR(false, false, true, false); PT_EXTEND_ATTR(true, false, true, false); PT_EXTEND_ATTR(false, true, true, false); PT_EXTEND_ATTR(true, true, true, false);
+    PT_EXTEND_ATTR(false, true, false, true); PT_EXTEND_ATTR(true, true, false, true); PT_EXTEND_ATTR(false, true, true, true); PT_EXTEND_ATTR(true, true, true, true);
 #undef PT_EXTEND_ATTR
   }
-#define PT_LAUNCH_EXTEND(C, D, P)                                                                                           \
-  hipLaunchKernelGGL((k_extend<C, D, P>), dim3(cfg.extend_blocks), dim3(256), lds, s, sc.nodes, sc.tris, ray_o, ray_d, hits, count, \
-                     work_cursor, stats, lds_entries, spill_entries, sc.spill, stride, cfg.fetch_min, cfg.postpone_pct, dq, any_hit ? 1u : 0u, sc.scene_mag, top_nodes, cfg.continue_pct, primary_gen)
-#define PT_LAUNCH_EXTEND2(C, D) do { if (sc.paired) PT_LAUNCH_EXTEND(C, D, true); else PT_LAUNCH_EXTEND(C, D, false); } while (0)
+#define PT_LAUNCH_EXTEND(C, D, P, S)                                                                                           \
+  hipLaunchKernelGGL((k_extend<C, D, P, S>), dim3(cfg.extend_blocks), dim3(256), lds, s, sc.nodes, sc.tris, ray_o, ray_d, hits, count, \
+                     work_cursor, stats, lds_entries, spill_entries, sc.spill, stride, cfg.fetch_min, postpone_pct, dq, any_hit ? 1u : 0u, sc.scene_mag, top_nodes, continue_pct, primary_gen)
+#define PT_LAUNCH_EXTEND2(C, D, S) do { if (sc.paired) PT_LAUNCH_EXTEND(C, D, true, S); else PT_LAUNCH_EXTEND(C, D, false, S); } while (0)
   if (cfg.no_private_segment) {   // pt_trace_rays_device_noalloc: the instantiations that use no scratch memory (never the counting ones)
 #define PT_LAUNCH_EXTEND_NS(D, P)                                                                                            \
-  hipLaunchKernelGGL((k_extend_ns<false, D, P>), dim3(cfg.extend_blocks), dim3(256), lds, s, sc.nodes, sc.tris, ray_o, ray_d, hits, count, \
-                     work_cursor, stats, lds_entries, spill_entries, sc.spill, stride, cfg.fetch_min, cfg.postpone_pct, dq, any_hit ? 1u : 0u, sc.scene_mag, top_nodes, cfg.continue_pct, primary_gen)
+  hipLaunchKernelGGL((k_extend_ns<false, D, P, false>), dim3(cfg.extend_blocks), dim3(256), lds, s, sc.nodes, sc.tris, ray_o, ray_d, hits, count, \
+                     work_cursor, stats, lds_entries, spill_entries, sc.spill, stride, cfg.fetch_min, postpone_pct, dq, any_hit ? 1u : 0u, sc.scene_mag, top_nodes, continue_pct, primary_gen)
     if (lds > 64 * 1024) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_extend_ns<false, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_extend_ns<false, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_extend_ns<false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_extend_ns<false, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_extend_ns<false, true, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_extend_ns<false, true, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_extend_ns<false, false, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_extend_ns<false, false, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     }
     if (dq > 0) { if (sc.paired) PT_LAUNCH_EXTEND_NS(true, true); else PT_LAUNCH_EXTEND_NS(true, false); }
     else { if (sc.paired) PT_LAUNCH_EXTEND_NS(false, true); else PT_LAUNCH_EXTEND_NS(false, false); }
 #undef PT_LAUNCH_EXTEND_NS
+  } else if (shared) {
+    if (count_traversal) PT_LAUNCH_EXTEND2(true, true, true); else PT_LAUNCH_EXTEND2(false, true, true);
   } else if (dq > 0) {
-    if (count_traversal) PT_LAUNCH_EXTEND2(true, true); else PT_LAUNCH_EXTEND2(false, true);
+    if (count_traversal) PT_LAUNCH_EXTEND2(true, true, false); else PT_LAUNCH_EXTEND2(false, true, false);
   } else {
-    if (count_traversal) PT_LAUNCH_EXTEND2(true, false); else PT_LAUNCH_EXTEND2(false, false);
+    if (count_traversal) PT_LAUNCH_EXTEND2(true, false, false); else PT_LAUNCH_EXTEND2(false, false, false);
   }
 #undef PT_LAUNCH_EXTEND2
 #undef PT_LAUNCH_EXTEND
@@ -1011,8 +1030,8 @@ void launch_extend(const DeviceScene& sc, const float4* ray_o, const float4* ray
 // decides that, so it is asked here: bytes of private segment of the instantiation that would be launched.
 int extend_ns_private_bytes(bool defer, bool paired, size_t* bytes_out) {
   hipFuncAttributes a;
-  const void* f = paired ? (defer ? reinterpret_cast<const void*>(&k_extend_ns<false, true, true>) : reinterpret_cast<const void*>(&k_extend_ns<false, false, true>))
-                         : (defer ? reinterpret_cast<const void*>(&k_extend_ns<false, true, false>) : reinterpret_cast<const void*>(&k_extend_ns<false, false, false>));
+  const void* f = paired ? (defer ? reinterpret_cast<const void*>(&k_extend_ns<false, true, true, false>) : reinterpret_cast<const void*>(&k_extend_ns<false, false, true, false>))
+                         : (defer ? reinterpret_cast<const void*>(&k_extend_ns<false, true, false, false>) : reinterpret_cast<const void*>(&k_extend_ns<false, false, false, false>));
   const hipError_t e = hipFuncGetAttributes(&a, f);
   if (e != hipSuccess) return (int)e;
   *bytes_out = a.localSizeBytes;

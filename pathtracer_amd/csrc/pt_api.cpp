@@ -100,6 +100,16 @@ struct pt_ctx {
   uint32_t packet_choice_w = 0, packet_choice_h = 0;
   float packet_cal_ms[2] = {0.0f, 0.0f};   // what it measured: k_extend, k_extend_packet
   uint64_t packet_launches = 0;
+  // PT_OPT_SHARED_TRIANGLE_PHASE: 0 = per-lane triangle tests, 1 = shared triangle phase (kernels.hip), 2 = whichever traces
+  // this scene's secondary rays faster: the first large batch of a scene runs its bounce-1 queue twice more under HIP
+  // events (same hit records every time), and the next call reads them. Until then: per-lane.
+  int shared_tri = 2;
+  int shared_choice = -1;             // -1 = not timed yet
+  bool shared_cal_pending = false;
+  std::pair<hipEvent_t, hipEvent_t> shared_cal_ev[2] = {{nullptr, nullptr}, {nullptr, nullptr}};   // per-lane, shared
+  float shared_cal_ms[2] = {0.0f, 0.0f};
+  bool shared_possible = true;        // record indices fit the phase's 26-bit list entries
+  uint64_t shared_launches = 0;
   int noalloc_blocks = 0;             // grid of pt_trace_rays_device_noalloc's extend instantiation (extend_grid)
   int packet_blocks = 0;              // its persistent grid (CUs x occupancy), looked up on first use per scene
   bool last_render_fused = false;     // the bounce-0 queue of the last pt_render was never written (pt_debug_read_queue)
@@ -329,6 +339,27 @@ int check_consts(pt_ctx* ctx, const PtRtConsts* c, bool need_sky) {
   return PT_OK;
 }
 
+bool use_shared_tri(const pt_ctx* ctx) {
+  return ctx->shared_possible && ctx->cfg.defer_entries > 0 && (ctx->shared_tri == 1 || (ctx->shared_tri == 2 && ctx->shared_choice == 1));
+}
+
+// Reads the two timings of calibrate_shared_tri once they are there (blocks only if that batch is still running). The shared
+// phase must win by 2 %: within the timing noise the per-lane kernel is kept, so the choice is reproducible from run to run.
+int resolve_shared_cal(pt_ctx* ctx) {
+  if (!ctx->shared_cal_pending) return PT_OK;
+  ctx->shared_cal_pending = false;
+  PT_HIP(hipEventSynchronize(ctx->shared_cal_ev[0].second));
+  for (int i = 0; i < 2; ++i) {
+    ctx->shared_cal_ms[i] = 0.0f;
+    PT_HIP(hipEventElapsedTime(&ctx->shared_cal_ms[i], ctx->shared_cal_ev[i].first, ctx->shared_cal_ev[i].second));
+    ctx->event_pool.push_back(ctx->shared_cal_ev[i]);
+    ctx->shared_cal_ev[i] = {nullptr, nullptr};
+  }
+  if (ctx->shared_cal_ms[0] < 0.2f) return PT_OK;   // a near-empty queue says nothing: time a later batch
+  ctx->shared_choice = ctx->shared_cal_ms[1] <= 0.98f * ctx->shared_cal_ms[0] ? 1 : 0;
+  return PT_OK;
+}
+
 void extend_one(pt_ctx* ctx, const float4* ro, const float4* rd, uint32_t stride, float4* hits, const uint32_t* count, uint32_t* cursor, int bounce = 0,
                 bool any_hit = false, int lane = 0, const float4* primary_gen = nullptr, bool packet = false, uint64_t max_rays = 0) {
   const hipStream_t st = lane >= 2 ? ctx->fl[lane - 2].stream : (lane ? ctx->stream2 : ctx->stream);
@@ -348,16 +379,22 @@ void extend_one(pt_ctx* ctx, const float4* ro, const float4* rd, uint32_t stride
     DeviceScene ds2 = ctx->ds;
     ds2.spill = ctx->fl[lane - 2].spill;
     LaunchCfg cfg2 = ctx->cfg;
+    cfg2.shared_tri = use_shared_tri(ctx);
     const uint64_t grid_div = 512u;   // rays per block: 256 / 512 / 1024 / 2048 measured, 512 best by 5-8 %
     if (max_rays) cfg2.extend_blocks = (int)std::min<uint64_t>((uint64_t)cfg2.extend_blocks, std::max<uint64_t>((uint64_t)cfg2.num_cus, (max_rays + grid_div - 1) / grid_div));
     launch_extend(ds2, ro, rd, stride, hits, count, cursor, ctx->fl[lane - 2].wb.stats, ctx->count_traversal, any_hit, cfg2, st, primary_gen);
   } else if (lane) {
     DeviceScene ds2 = ctx->ds;
     ds2.spill = ctx->spill2;
-    launch_extend(ds2, ro, rd, stride, hits, count, cursor, ctx->wb2.stats, ctx->count_traversal, any_hit, ctx->cfg, st, primary_gen);
+    LaunchCfg cfg2 = ctx->cfg;
+    cfg2.shared_tri = use_shared_tri(ctx);
+    launch_extend(ds2, ro, rd, stride, hits, count, cursor, ctx->wb2.stats, ctx->count_traversal, any_hit, cfg2, st, primary_gen);
   } else {
-    launch_extend(ctx->ds, ro, rd, stride, hits, count, cursor, ctx->wb.stats, ctx->count_traversal, any_hit, ctx->cfg, st, primary_gen);
+    LaunchCfg cfg2 = ctx->cfg;
+    cfg2.shared_tri = use_shared_tri(ctx);
+    launch_extend(ctx->ds, ro, rd, stride, hits, count, cursor, ctx->wb.stats, ctx->count_traversal, any_hit, cfg2, st, primary_gen);
   }
+  if (!packet && use_shared_tri(ctx)) ctx->shared_launches++;
   ctx->extend_launches++;
   ctx->extend_launches_bounce[std::min(15, std::max(0, bounce))]++;
   if (ctx->time_kernels) {
@@ -407,6 +444,27 @@ int calibrate_primary_kernel(pt_ctx* ctx, const PtRtConsts& consts, uint32_t wid
   return PT_OK;
 }
 
+// PT_OPT_SHARED_TRIANGLE_PHASE = 2: the bounce-1 queue of a batch (incoherent rays, already traced once by the caller: caches
+// warm, hit records in place) is traced again by the shared-phase instantiation and then by the per-lane one, each under a
+// pair of events. Every run writes the same hit records, so the render goes on unchanged; nothing waits here.
+int calibrate_shared_tri(pt_ctx* ctx, WavefrontBuffers& wb, uint32_t bounce) {
+  const int in = (int)(bounce & 1u);
+  uint32_t* count = wb.counters + CTR_AT(CTR_QCOUNT0 + bounce);
+  uint32_t* cursor = wb.counters + CTR_AT(CTR_WORK0 + bounce);
+  for (int pass = 0; pass < 2; ++pass) {
+    const int which = pass == 0 ? 1 : 0;   // shared first, per-lane second
+    ctx->shared_cal_ev[which] = get_event_pair(ctx);
+    LaunchCfg cfg = ctx->cfg;
+    cfg.shared_tri = which == 1;
+    PT_HIP(hipMemsetAsync(cursor, 0, sizeof(uint32_t), ctx->stream));
+    PT_HIP(hipEventRecord(ctx->shared_cal_ev[which].first, ctx->stream));
+    launch_extend(ctx->ds, wb.ray_o[in], wb.ray_d[in], 1, wb.hits, count, cursor, wb.stats, false, false, cfg, ctx->stream, nullptr);
+    PT_HIP(hipEventRecord(ctx->shared_cal_ev[which].second, ctx->stream));
+  }
+  ctx->shared_cal_pending = true;
+  return PT_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -453,6 +511,7 @@ int pt_destroy(pt_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   collect_events(ctx);
+  (void)resolve_shared_cal(ctx);   // hands its events back to the pool
   for (auto& p : ctx->event_pool) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
   free_list(ctx->scene_allocs);
   if (ctx->instance_ext) (void)hipFree(ctx->instance_ext);
@@ -497,7 +556,7 @@ int pt_set_stream(pt_ctx* ctx, void* hip_stream) {
 int pt_synchronize(pt_ctx* ctx) {
   PT_REQUIRE_CTX();
   PT_HIP(hipStreamSynchronize(ctx->stream));
-  return PT_OK;
+  return resolve_shared_cal(ctx);   // free by now
 }
 
 int pt_set_option(pt_ctx* ctx, int option, int64_t value) {
@@ -520,6 +579,7 @@ int pt_set_option(pt_ctx* ctx, int option, int64_t value) {
       ctx->frame_lanes = (int)value;
       return PT_OK;
     case PT_OPT_PRIMARY_PACKET: ctx->primary_packet = value < 0 ? 0 : (value > 2 ? 2 : (int)value); return PT_OK;
+    case PT_OPT_SHARED_TRIANGLE_PHASE: ctx->shared_tri = value < 0 ? 0 : (value > 2 ? 2 : (int)value); return PT_OK;
     case PT_OPT_FUSED_PRIMARY:
       if (value != 0 && value != 1) return ctx->fail(PT_ERR_INVALID_ARG, "PT_OPT_FUSED_PRIMARY must be 0 or 1");
       ctx->fused_primary = value != 0;
@@ -543,6 +603,22 @@ int pt_debug_set_tuning(pt_ctx* ctx, int knob, int64_t value) {
     case PT_TUNE_EXTEND_CONTINUE_PCT:
       if (value < 0 || value > 100) return ctx->fail(PT_ERR_INVALID_ARG, "continue_pct must be 0..100");
       ctx->cfg.continue_pct = (uint32_t)value;
+      return PT_OK;
+    case PT_TUNE_SHARED_DEFER:
+      if (value < 1 || value > 16) return ctx->fail(PT_ERR_INVALID_ARG, "shared phase: parked groups per lane must be 1..16");
+      ctx->cfg.sh_defer_entries = (uint32_t)value;
+      return PT_OK;
+    case PT_TUNE_SHARED_TOP_NODES:
+      if (value < 0 || value > 585) return ctx->fail(PT_ERR_INVALID_ARG, "top_nodes must be 0..585");
+      ctx->cfg.sh_top_nodes = (uint32_t)value;
+      return PT_OK;
+    case PT_TUNE_SHARED_POSTPONE_PCT:
+      if (value < 0 || value > 100) return ctx->fail(PT_ERR_INVALID_ARG, "postpone_pct must be 0..100");
+      ctx->cfg.sh_postpone_pct = (uint32_t)value;
+      return PT_OK;
+    case PT_TUNE_SHARED_CONTINUE_PCT:
+      if (value < 0 || value > 100) return ctx->fail(PT_ERR_INVALID_ARG, "continue_pct must be 0..100");
+      ctx->cfg.sh_continue_pct = (uint32_t)value;
       return PT_OK;
     case PT_TUNE_EXTEND_LDS_STACK:
       if (value < 1 || value > 128) return ctx->fail(PT_ERR_INVALID_ARG, "LDS stack entries must be 1..128");
@@ -643,6 +719,7 @@ int pt_scene_create(pt_ctx* ctx, const PtMeshDesc* meshes, uint32_t num_meshes, 
   ctx->ds.tris = d_tris;
   ctx->ds.paired = bvh.paired;
   ctx->num_records = bvh.num_records();
+  ctx->shared_possible = bvh.num_records() < (1ull << 26);
   ctx->ds.prim_data = d_prim;
   ctx->ds.vertex_uv = d_uv;
   ctx->ds.prim_shade = d_ps;
@@ -677,6 +754,9 @@ int pt_scene_create(pt_ctx* ctx, const PtMeshDesc* meshes, uint32_t num_meshes, 
   ctx->has_scene = true;
   ctx->packet_blocks = 0;   // depends on the scene (stack depth, record format)
   ctx->packet_choice = -1;
+  if (ctx->shared_cal_pending) (void)resolve_shared_cal(ctx);   // hands the events back
+  ctx->shared_choice = -1;
+  ctx->shared_cal_ms[0] = ctx->shared_cal_ms[1] = 0.0f;
   return PT_OK;
 }
 
@@ -933,6 +1013,11 @@ int pt_render(pt_ctx* ctx, const PtRtConsts* consts, uint32_t width, uint32_t he
   if (use_skyview) launch_skyview_lut(*consts, ctx->lut, ctx->skyview, ctx->stream);   // 64 Ki texels, a few microseconds
   const bool fused = ctx->fused_primary;   // primaries computed inside k_extend / k_shade instead of a k_generate pass
   ctx->last_render_fused = fused;
+  if ((rc = resolve_shared_cal(ctx)) != PT_OK) return rc;
+  // time the two triangle-phase variants on this call's first batch? (large batches only: the timing has to see the kernels
+  // at throughput; never while the caller is collecting statistics or timings of its own)
+  bool calibrate_shared = ctx->shared_tri == 2 && ctx->shared_choice < 0 && ctx->shared_possible && ctx->cfg.defer_entries > 0 && bounces >= 2 &&
+                          !ctx->count_traversal && !ctx->time_kernels && wh * std::min<uint64_t>(spb, num_samples) >= (1ull << 21);
   bool packet = fused && ctx->primary_packet == 1 && !ctx->count_traversal;
   if (fused && ctx->primary_packet == 2 && !ctx->count_traversal) {
     if (ctx->packet_choice < 0 || ctx->packet_choice_w != width || ctx->packet_choice_h != height) {
@@ -968,6 +1053,10 @@ int pt_render(pt_ctx* ctx, const PtRtConsts* consts, uint32_t width, uint32_t he
         WavefrontBuffers& wb = *wbs[l];
         extend_one(ctx, wb.ray_o[in], wb.ray_d[in], 1, wb.hits, wb.counters + CTR_AT(CTR_QCOUNT0 + b), wb.counters + CTR_AT(CTR_WORK0 + b), (int)b, false, l,
                    (fused && b == 0) ? wb.gen : nullptr, /*packet=*/packet && b == 0);
+        if (calibrate_shared && b == 1 && l == 0) {
+          calibrate_shared = false;
+          if ((rc = calibrate_shared_tri(ctx, wb, b)) != PT_OK) return rc;
+        }
         launch_shade(*consts, ctx->ds, wb, (int)b, width, height, first_lane[l], wh * k_lane[l], ctx->russian_roulette, ctx->cfg, streams[l], fused);
       }
     }
@@ -1271,6 +1360,10 @@ int pt_stats_get(pt_ctx* ctx, PtStats* out) {
   memset(out, 0, sizeof(*out));
   PT_HIP(hipStreamSynchronize(ctx->stream));
   collect_events(ctx);
+  {
+    const int rc = resolve_shared_cal(ctx);
+    if (rc != PT_OK) return rc;
+  }
   std::vector<const WavefrontBuffers*> all_wb{&ctx->wb, &ctx->wb2};   // pipeline and frame lanes
   for (const auto& L : ctx->fl) all_wb.push_back(&L.wb);
   for (const WavefrontBuffers* wb : all_wb) {
@@ -1292,6 +1385,10 @@ int pt_stats_get(pt_ctx* ctx, PtStats* out) {
   out->packet_launches = ctx->packet_launches;
   out->packet_cal_ms[0] = ctx->packet_cal_ms[0];
   out->packet_cal_ms[1] = ctx->packet_cal_ms[1];
+  out->shared_launches = ctx->shared_launches;
+  out->shared_cal_ms[0] = ctx->shared_cal_ms[0];
+  out->shared_cal_ms[1] = ctx->shared_cal_ms[1];
+  out->shared_choice = ctx->shared_choice;
   for (int b = 0; b < 16; ++b) out->extend_launches_bounce[b] = ctx->extend_launches_bounce[b];
   out->extend_ms = ctx->extend_ms;
   out->render_ms = ctx->render_ms;
@@ -1309,6 +1406,7 @@ int pt_stats_reset(pt_ctx* ctx) {
   ctx->render_ms = 0.0;
   ctx->extend_launches = 0;
   ctx->packet_launches = 0;
+  ctx->shared_launches = 0;
   for (int b = 0; b < 16; ++b) ctx->extend_launches_bounce[b] = 0;
   for (int b = 0; b < 16; ++b) ctx->extend_ms_bounce[b] = 0.0;
   if (ctx->wb.stats) PT_HIP(hipMemset(ctx->wb.stats, 0, ST_WORDS * sizeof(unsigned long long)));

@@ -814,15 +814,18 @@ def test_bench_gpus_2_starts_two_ranks_by_itself():
 
 
 # ---------------------------------------------------------------------------------------------- schedule options
-@pytest.mark.parametrize("fetch_min,postpone,blocks,lds_stack,defer", [
-    (16, 40, 0, 6, 4),      # the shipped defaults (csrc/kernels.h LaunchCfg), set explicitly
-    (16, 50, 0, 8, 4),      # round-1 schedule: 50 % postpone threshold, 8-entry LDS stack
-    (1, 0, 1, 1, 0),        # stack postponing off, one LDS stack entry: everything deeper goes through the global spill
-    (64, 100, 2, 2, 1),     # refill only when the whole wave is idle, always postpone, one parked group
-    (32, 25, 3, 3, 16),     # large deferred queue
-    (8, 75, 0, 128, 0),     # whole stack in LDS (more than 64 KB of dynamic LDS), stack postponing
+@pytest.mark.parametrize("fetch_min,postpone,blocks,lds_stack,defer,shared", [
+    (16, 40, 0, 6, 4, 0),      # the shipped defaults (csrc/kernels.h LaunchCfg), set explicitly
+    (16, 50, 0, 8, 4, 0),      # round-1 schedule: 50 % postpone threshold, 8-entry LDS stack
+    (1, 0, 1, 1, 0, 0),        # stack postponing off, one LDS stack entry: everything deeper goes through the global spill
+    (64, 100, 2, 2, 1, 0),     # refill only when the whole wave is idle, always postpone, one parked group
+    (32, 25, 3, 3, 16, 0),     # large deferred queue
+    (8, 75, 0, 128, 0, 0),     # whole stack in LDS (more than 64 KB of dynamic LDS), stack postponing
+    (16, 25, 0, 6, 3, 1),      # shared triangle phase, its shipped schedule
+    (64, 100, 2, 2, 1, 1),     # shared triangle phase: one parked group (every second group forces a pass), two LDS stack entries
+    (4, 0, 0, 128, 16, 1),     # shared triangle phase at once, large queue, more than 64 KB of dynamic LDS
 ])
-def test_extend_schedule_options_never_change_hits(ctx, oracle, fetch_min, postpone, blocks, lds_stack, defer):
+def test_extend_schedule_options_never_change_hits(ctx, oracle, fetch_min, postpone, blocks, lds_stack, defer, shared):
     """The PT_TUNE_EXTEND_* knobs (include/pt_api_tuning.h) only reorder work inside the traversal kernel: closest hits stay bit-identical to
     the oracle and occlusion answers stay equal, including through the global stack-spill path."""
     sc = scenes.atrium(1)
@@ -831,15 +834,23 @@ def test_extend_schedule_options_never_change_hits(ctx, oracle, fetch_min, postp
     info = ctx.scene_info()
     rays = random_rays(31, 150000, list(info.bounds_min), list(info.bounds_max), tmin=0.001, tmax=10000.0)
     ref = osc.trace_rays(rays)
-    opts = ((api.PT_TUNE_EXTEND_FETCH_MIN, fetch_min, 16), (api.PT_TUNE_EXTEND_POSTPONE_PCT, postpone, 40),
-            (api.PT_TUNE_EXTEND_BLOCKS_PER_CU, blocks, 0), (api.PT_TUNE_EXTEND_LDS_STACK, lds_stack, 6),
-            (api.PT_TUNE_EXTEND_DEFER, defer, 4))
+    if shared:
+        opts = ((api.PT_TUNE_EXTEND_FETCH_MIN, fetch_min, 16), (api.PT_TUNE_SHARED_POSTPONE_PCT, postpone, 25), (api.PT_TUNE_SHARED_CONTINUE_PCT, postpone, 50),
+                (api.PT_TUNE_EXTEND_BLOCKS_PER_CU, blocks, 0), (api.PT_TUNE_EXTEND_LDS_STACK, lds_stack, 6), (api.PT_TUNE_SHARED_DEFER, defer, 3))
+    else:
+        opts = ((api.PT_TUNE_EXTEND_FETCH_MIN, fetch_min, 16), (api.PT_TUNE_EXTEND_POSTPONE_PCT, postpone, 40),
+                (api.PT_TUNE_EXTEND_BLOCKS_PER_CU, blocks, 0), (api.PT_TUNE_EXTEND_LDS_STACK, lds_stack, 6),
+                (api.PT_TUNE_EXTEND_DEFER, defer, 4))
     try:
+        ctx.set_option(api.PT_OPT_SHARED_TRIANGLE_PHASE, shared)
+        ctx.stats_reset()
         for o, v, _ in opts:
             ctx.set_tuning(o, v)
         got = ctx.trace_rays(rays)
         occ = ctx.occluded(rays)
+        assert (ctx.stats().shared_launches > 0) == bool(shared)
     finally:
+        ctx.set_option(api.PT_OPT_SHARED_TRIANGLE_PHASE, 2)
         for o, _, d in opts:
             ctx.set_tuning(o, d)
     assert np.array_equal(got["prim"], ref["prim"])
@@ -847,6 +858,96 @@ def test_extend_schedule_options_never_change_hits(ctx, oracle, fetch_min, postp
     for f in ("t", "u", "v"):
         assert np.array_equal(got[f][hit].view(np.uint32), ref[f][hit].view(np.uint32)), f
     assert np.array_equal(occ.astype(bool), hit)
+
+
+@pytest.mark.parametrize("pairs", [False, True], ids=["48-byte-triangles", "64-byte-pairs"])
+def test_shared_triangle_phase_gives_the_same_hit_records(ctx, oracle, pairs):
+    """PT_OPT_SHARED_TRIANGLE_PHASE = 1: the wave pools the pending leaf records of its 64 rays and tests them 64 at a time; a
+    hit travels back to its ray through an LDS minimum on (t, triangle id). Closest hits (ties, t == tmax, duplicated
+    references of the spatial splits included) must be bit-identical to the oracle's and to the per-lane phase, the counted
+    counting instantiation must give the same records, and occlusion answers must agree."""
+    sc = scenes.atrium(1)
+    ctx.scene_create(sc, api.PT_SCENE_PAIR_TRIANGLES if pairs else api.PT_SCENE_NO_PAIRS)
+    osc = oracle.scene(sc)
+    info = ctx.scene_info()
+    rays = random_rays(41, 200000, list(info.bounds_min), list(info.bounds_max), tmin=0.001, tmax=10000.0)
+    # a block of rays whose tmax IS the distance of their closest hit: t == tmax is not a hit (exclusive interval), and the
+    # shared phase has to reproduce that through its integer key
+    ref0 = osc.trace_rays(rays[:20000])
+    h = ref0["prim"] != api.PT_MISS
+    rays["tmax"][:20000][h] = ref0["t"][h]
+    ref = osc.trace_rays(rays)
+    try:
+        ctx.set_option(api.PT_OPT_SHARED_TRIANGLE_PHASE, 0)
+        lane = ctx.trace_rays(rays)
+        ctx.set_option(api.PT_OPT_SHARED_TRIANGLE_PHASE, 1)
+        ctx.stats_reset()
+        got = ctx.trace_rays(rays)
+        occ = ctx.occluded(rays)
+        st = ctx.stats()
+        assert st.shared_launches >= 2
+        ctx.set_option(api.PT_OPT_COUNT_TRAVERSAL, 1)
+        ctx.stats_reset()
+        got_counted = ctx.trace_rays(rays)
+        stc = ctx.stats()
+    finally:
+        ctx.set_option(api.PT_OPT_COUNT_TRAVERSAL, 0)
+        ctx.set_option(api.PT_OPT_SHARED_TRIANGLE_PHASE, 2)
+    assert np.array_equal(got.view(np.uint32), lane.view(np.uint32))
+    assert np.array_equal(got_counted.view(np.uint32), lane.view(np.uint32))
+    assert np.array_equal(got["prim"], ref["prim"])
+    hit = ref["prim"] != api.PT_MISS
+    assert 0.3 < hit.mean() < 0.99
+    for f in ("t", "u", "v"):
+        assert np.array_equal(got[f][hit].view(np.uint32), ref[f][hit].view(np.uint32)), f
+    assert np.array_equal(occ.astype(bool), hit)
+    assert stc.tris_tested > 0 and stc.tri_wave_steps > 0
+
+
+def test_shared_triangle_phase_auto_choice_times_both_and_keeps_the_image(ctx, oracle):
+    """PT_OPT_SHARED_TRIANGLE_PHASE = 2 (default): the first large batch of a scene traces its bounce-1 queue twice more under
+    events; a later call reads the timings and fixes the choice. The accumulated image is the same bits as with the option
+    off, whatever it chose."""
+    atm = oracle.earth_atmosphere()
+    ctx.sky_set(atm)
+    sc = scenes.atrium(1)
+    w, h, spp = 1024, 576, 4          # 2.4 M paths per batch: above the 2^21 the timing asks for
+    c = lookat_consts(w, h, scenes.ATRIUM_CAM, depth=3)
+    imgs = []
+    for opt in (0, 2):
+        ctx.scene_create(sc)
+        ctx.set_option(api.PT_OPT_SHARED_TRIANGLE_PHASE, opt)
+        ctx.accum_reset(w, h)
+        ctx.stats_reset()
+        ctx.render(c, w, h, 0, spp)
+        ctx.render(c, w, h, spp, spp)
+        st = ctx.stats()
+        imgs.append(ctx.accum_read_sum()[0].copy())
+        if opt == 0:
+            assert st.shared_choice == -1 and st.shared_launches == 0
+        else:
+            assert st.shared_choice in (0, 1)
+            assert st.shared_cal_ms[0] > 0.2 and st.shared_cal_ms[1] > 0.2
+            assert (st.shared_launches > 0) == (st.shared_choice == 1)
+    # forced on, counted: the same bits again, and the phase fills its rounds (per-lane phase on this scene: 0.49 of the
+    # lanes test a record per wave-step; the review's bar for the shared form was 0.70 with the node phase above 0.75)
+    try:
+        ctx.scene_create(sc)
+        ctx.set_option(api.PT_OPT_SHARED_TRIANGLE_PHASE, 1)
+        ctx.set_option(api.PT_OPT_COUNT_TRAVERSAL, 1)
+        ctx.accum_reset(w, h)
+        ctx.stats_reset()
+        ctx.render(c, w, h, 0, spp)
+        ctx.render(c, w, h, spp, spp)
+        st = ctx.stats()
+        img1 = ctx.accum_read_sum()[0].copy()
+    finally:
+        ctx.set_option(api.PT_OPT_COUNT_TRAVERSAL, 0)
+        ctx.set_option(api.PT_OPT_SHARED_TRIANGLE_PHASE, 2)
+    assert np.array_equal(imgs[0].view(np.uint32), imgs[1].view(np.uint32))
+    assert np.array_equal(imgs[0].view(np.uint32), img1.view(np.uint32))
+    tri_util, node_util = st.tris_tested / (64.0 * st.tri_wave_steps), st.nodes_visited / (64.0 * st.node_wave_steps)
+    assert tri_util > 0.70 and node_util > 0.75, (tri_util, node_util)
 
 
 # ---------------------------------------------------------------------------------------------- AO pipeline (Ao.hlsl)

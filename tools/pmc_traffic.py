@@ -45,7 +45,7 @@ if ke and acc[ke].get("GRBM_GUI_ACTIVE") and acc[ke].get("TA_TA_BUSY_sum"):
     out["extend_vmem_rd_wave_instr_per_launch"] = round(acc[ke]["SQ_INSTS_VMEM_RD"] / calls[ke]["SQ_INSTS_VMEM_RD"])
     out["extend_salu_instr_per_launch"] = round(acc[ke]["SQ_INSTS_SALU"] / calls[ke]["SQ_INSTS_SALU"])
     out["extend_l2_hit_rate"] = round(acc[ke]["TCC_HIT_sum"] / (acc[ke]["TCC_HIT_sum"] + acc[ke]["TCC_MISS_sum"]), 4)
-for extra in sys.argv[7:]:          # optional key=value pairs: material_ext=1 russian_roulette=1
+for extra in sys.argv[7:]:          # optional key=value pairs: material_ext=1 russian_roulette=1 shared_triangle_phase=1
     k, v = extra.split("=")
     out[k] = int(v)
 out["note"] = ("rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE (separate passes), mean over the k_extend launches of bench.py --steps 2; "
@@ -54,7 +54,8 @@ out["note"] = ("rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE (separate passes), mea
 path = "profiles/%s/pmc_traffic.json" % os.environ.get("PT_PROFILE_ROUND", "r03")
 os.makedirs(os.path.dirname(path), exist_ok=True)
 cur = json.load(open(path)) if os.path.exists(path) else []
-key = lambda c: (c["workload"], c["width"], c["height"], c["spp_per_step"], c["depth"], c.get("material_ext", 0), c.get("russian_roulette", 0))
+key = lambda c: (c["workload"], c["width"], c["height"], c["spp_per_step"], c["depth"], c.get("material_ext", 0), c.get("russian_roulette", 0),
+                 c.get("shared_triangle_phase", 0))
 cur = [c for c in cur if key(c) != key(out)] + [out]
 json.dump(cur, open(path, "w"), indent=1)
 print(json.dumps(out, indent=1))

@@ -11,18 +11,23 @@ mkdir -p gpurun_out/${TAG}_trace profiles/$TAG
 # the headline alone (no "configs" legs: their k_extend launches on other scenes would enter the per-kernel averages)
 timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${TAG}_trace -- python3 bench.py --no-cpu-baseline --no-configs > gpurun_out/${TAG}_trace/bench.json 2> gpurun_out/${TAG}_trace/bench.err || { echo "trace failed"; tail -3 gpurun_out/${TAG}_trace/bench.err; exit 1; }
 echo "trace ok"
-bash tools/prof_pmc.sh ${TAG}_atrium --primary-packet 1 || exit 1
-python3 tools/summarize_pmc.py ${TAG}_atrium > gpurun_out/pmc_${TAG}_atrium_summary.txt
-bash tools/prof_pmc.sh ${TAG}_street --workload street --primary-packet 1 || exit 1
-python3 tools/summarize_pmc.py ${TAG}_street > gpurun_out/pmc_${TAG}_street_summary.txt
-bash tools/prof_pmc.sh ${TAG}_street_hard --workload street_hard --primary-packet 1 || exit 1
-python3 tools/summarize_pmc.py ${TAG}_street_hard > gpurun_out/pmc_${TAG}_street_hard_summary.txt
-bash tools/prof_pmc.sh ${TAG}_courtyard --workload courtyard --width 3840 --height 2160 --spp-per-step 16 --russian-roulette 1 --primary-packet 1 || exit 1
-python3 tools/summarize_pmc.py ${TAG}_courtyard > gpurun_out/pmc_${TAG}_courtyard_summary.txt
-python3 tools/pmc_traffic.py ${TAG}_atrium atrium 1920 1080 64 4 > /dev/null || exit 1
-python3 tools/pmc_traffic.py ${TAG}_street street 1920 1080 64 8 > /dev/null || exit 1
-python3 tools/pmc_traffic.py ${TAG}_street_hard street_hard 1920 1080 64 8 > /dev/null || exit 1
-python3 tools/pmc_traffic.py ${TAG}_courtyard courtyard 3840 2160 16 16 russian_roulette=1 > /dev/null || exit 1
+# which triangle phase does the library pick per workload (PT_OPT_SHARED_TRIANGLE_PHASE = 2 times both forms on the warm-up step)?
+# The PMC passes then name it explicitly, like the primary kernel, so no timing launch enters the per-launch averages.
+choice() {
+  timeout -k 10 300 python3 bench.py --no-cpu-baseline --no-configs --steps 1 --warmup 1 "$@" 2> /dev/null | python3 -c "import json,sys; print(max(0, json.loads(sys.stdin.read().strip().splitlines()[-1])['roofline']['triangle_phase']['choice']))"
+}
+pmc_one() {   # <name> <w> <h> <spp> <depth> <extra pmc_traffic key=value or ''> <bench args...>
+  local name=$1 w=$2 h=$3 spp=$4 depth=$5 extra=$6; shift 6
+  local ch; ch=$(choice "$@") || exit 1
+  echo "$name: triangle phase $ch"
+  bash tools/prof_pmc.sh ${TAG}_$name "$@" --primary-packet 1 --shared-triangle-phase $ch || exit 1
+  python3 tools/summarize_pmc.py ${TAG}_$name > gpurun_out/pmc_${TAG}_${name}_summary.txt
+  python3 tools/pmc_traffic.py ${TAG}_$name $name $w $h $spp $depth $extra shared_triangle_phase=$ch > /dev/null || exit 1
+}
+pmc_one atrium 1920 1080 64 4 "" --workload atrium
+pmc_one street 1920 1080 64 8 "" --workload street
+pmc_one street_hard 1920 1080 64 8 "" --workload street_hard
+pmc_one courtyard 3840 2160 16 16 russian_roulette=1 --workload courtyard --width 3840 --height 2160 --spp-per-step 16 --russian-roulette 1
 cp profiles/$TAG/pmc_traffic.json gpurun_out/pmc_traffic_${TAG}.json
 echo "pmc ok"
 bash tools/run_round_numbers.sh
