@@ -30,4 +30,5 @@ pmc_one street_hard 1920 1080 64 8 "" --workload street_hard
 pmc_one courtyard 3840 2160 16 16 russian_roulette=1 --workload courtyard --width 3840 --height 2160 --spp-per-step 16 --russian-roulette 1
 cp profiles/$TAG/pmc_traffic.json gpurun_out/pmc_traffic_${TAG}.json
 echo "pmc ok"
-bash tools/run_round_numbers.sh
+# (SKIP_ROUND=1: the bench lines run in a call of their own, after pmc_traffic.json has been copied into profiles/<round>/)
+[ "${SKIP_ROUND:-0}" = 1 ] || bash tools/run_round_numbers.sh

@@ -6,6 +6,8 @@ T="timeout -k 10 400"
 $T python -u bench.py > gpurun_out/round/bench_default.json 2> gpurun_out/round/bench_default.err
 $T python -u bench.py --no-cpu-baseline --no-roofline --pipeline 1 > gpurun_out/round/bench_atrium_pipeline.json 2>/dev/null
 $T python -u bench.py --no-cpu-baseline --no-roofline --pipeline 1 --sky-mode 1 > gpurun_out/round/bench_atrium_pipeline_skylut.json 2>/dev/null
+$T python -u bench.py --workload street_hard --no-cpu-baseline --no-configs > gpurun_out/round/bench_street_hard.json 2>/dev/null
+$T python -u bench.py --workload street_hard --no-cpu-baseline --no-configs --shared-triangle-phase 0 > gpurun_out/round/bench_street_hard_per_lane_phase.json 2>/dev/null
 $T python -u bench.py --workload street --no-cpu-baseline --no-roofline --material-ext 1 --russian-roulette 1 > gpurun_out/round/bench_street_ext_rr.json 2>/dev/null
 $T python -u bench.py --workload courtyard --width 3840 --height 2160 --spp-per-step 16 --no-cpu-baseline --no-configs > gpurun_out/round/bench_courtyard_no_rr.json 2>/dev/null
 $T python -u bench.py --workload courtyard --width 3840 --height 2160 --spp-per-step 16 --no-cpu-baseline --no-roofline --material-ext 1 --russian-roulette 1 > gpurun_out/round/bench_courtyard_ext_rr.json 2>/dev/null
