@@ -10,6 +10,7 @@
 #include <chrono>
 #include <cmath>
 #include <condition_variable>
+#include <cstdio>
 #include <cstring>
 #include <deque>
 #include <mutex>
@@ -51,6 +52,9 @@ struct Box3 {
   double area() const { return valid() ? half_area(lo, hi) : 0.0; }
 };
 
+#ifndef PT_BVH_REINSERT_PASSES_DEFAULT
+#define PT_BVH_REINSERT_PASSES_DEFAULT 0
+#endif
 #ifndef PT_BVH_BINS
 #define PT_BVH_BINS 16
 #endif
@@ -436,6 +440,183 @@ class SplitBuilder {
   std::vector<Task> tasks_;
 };
 
+// Insertion-based optimisation of the finished binary tree (after Bittner, Hapala, Havran: "Fast insertion-based optimization
+// of bounding volume hierarchies", CGF 2013). A top-down builder fixes every split before it has seen what happens below it;
+// here the nodes with the largest boxes are taken out again — node N and its parent leave the tree, N's sibling moves up —
+// and N's two subtrees are put back, each at the place where it adds the least surface area to the tree (branch and bound
+// over "area added to the ancestors so far", cheapest first). The tree's SAH cost can only fall: putting a subtree back
+// where it came from is always among the candidates. Sequential and deterministic; hit records cannot depend on it.
+// Two forms, which find different trees (build_bvh8 keeps whichever gives the best 8-wide tree):
+//   careful = false: every pass works on the same slice (the largest nodes), and an operation may leave the area sum higher
+//                    than it found it (the second subtree goes back into a tree the first one changed);
+//   careful = true:  such an operation is undone, so the area sum never grows, and pass p works on the p-th slice by area.
+// Returns false when it gave up after the first pass (the tree is left as it came).
+static bool optimize_by_reinsertion(std::vector<Node2>& nodes, int passes, double fraction, size_t max_per_pass, bool careful) {
+  const uint32_t n = (uint32_t)nodes.size();
+  if (n < 64u || passes <= 0) return false;
+  constexpr uint32_t NONE = 0xFFFFFFFFu;
+  {   // the parallel builder hands out node ids in the order its threads get there; ties below are broken by id, so the
+      // nodes are first renumbered breadth-first (a function of the topology alone)
+    std::vector<Node2> bfs(n);
+    std::vector<uint32_t> old_of(n);
+    old_of[0] = 0;
+    uint32_t next = 1;
+    for (uint32_t i = 0; i < n; ++i) {
+      bfs[i] = nodes[old_of[i]];
+      if (bfs[i].left) { old_of[next] = bfs[i].left; old_of[next + 1] = bfs[i].left + 1; bfs[i].left = next; next += 2; }
+    }
+    nodes.swap(bfs);
+  }
+  std::vector<uint32_t> parent(n, NONE), c0(n, NONE), c1(n, NONE);
+  std::vector<double> area(n);
+  for (uint32_t i = 0; i < n; ++i) {
+    area[i] = half_area(nodes[i].lo, nodes[i].hi);
+    if (nodes[i].left) { c0[i] = nodes[i].left; c1[i] = nodes[i].left + 1; parent[c0[i]] = i; parent[c1[i]] = i; }
+  }
+  uint32_t root = 0;
+  double acc = 0.0;   // change of the area sum over the internal nodes since the current operation began
+  auto refit_up = [&](uint32_t i) {   // boxes of i and its ancestors from their children, until one does not change
+    while (i != NONE) {
+      Node2& nd = nodes[i];
+      const Node2 &a = nodes[c0[i]], &b = nodes[c1[i]];
+      float lo[3], hi[3];
+      for (int k = 0; k < 3; ++k) { lo[k] = std::min(a.lo[k], b.lo[k]); hi[k] = std::max(a.hi[k], b.hi[k]); }
+      if (memcmp(lo, nd.lo, 12) == 0 && memcmp(hi, nd.hi, 12) == 0) break;
+      memcpy(nd.lo, lo, 12); memcpy(nd.hi, hi, 12);
+      const double na = half_area(lo, hi);
+      acc += na - area[i];
+      area[i] = na;
+      i = parent[i];
+    }
+  };
+  // takes the internal node `q` out: its child `keep` moves up into q's place
+  auto unlink = [&](uint32_t q, uint32_t keep) {
+    const uint32_t g = parent[q];
+    acc -= area[q];
+    parent[keep] = g;
+    if (g == NONE) root = keep;
+    else { if (c0[g] == q) c0[g] = keep; else c1[g] = keep; refit_up(g); }
+  };
+  // puts the free node id `q` between x and x's parent, with children (x, sub)
+  auto link = [&](uint32_t q, uint32_t x, uint32_t sub) {
+    const uint32_t px = parent[x];
+    c0[q] = x; c1[q] = sub;
+    parent[q] = px; parent[x] = q; parent[sub] = q;
+    if (px == NONE) root = q;
+    else if (c0[px] == x) c0[px] = q; else c1[px] = q;
+    Node2& qn = nodes[q];
+    for (int k = 0; k < 3; ++k) { qn.lo[k] = std::min(nodes[x].lo[k], nodes[sub].lo[k]); qn.hi[k] = std::max(nodes[x].hi[k], nodes[sub].hi[k]); }
+    area[q] = half_area(qn.lo, qn.hi);
+    acc += area[q];
+    refit_up(px);
+  };
+  auto union_area = [&](uint32_t x, const Node2& s) {
+    const Node2& a = nodes[x];
+    float lo[3], hi[3];
+    for (int k = 0; k < 3; ++k) { lo[k] = std::min(a.lo[k], s.lo[k]); hi[k] = std::max(a.hi[k], s.hi[k]); }
+    return half_area(lo, hi);
+  };
+  struct Cand { double induced; uint32_t node; };
+  auto worse = [](const Cand& a, const Cand& b) { return a.induced > b.induced || (a.induced == b.induced && a.node > b.node); };
+  std::vector<Cand> heap;
+  auto reinsert = [&](uint32_t sub, uint32_t q) {   // subtree `sub` (detached) goes back under the free node id q
+    // (Seeding `best` with the place the subtree came from prunes the search a little earlier, but then that place wins every
+    // tie, and on regular geometry — many boxes of equal area — the 8-wide tree that comes out is measurably worse: atrium
+    // 13.8 instead of 13.4 node visits per secondary ray. Ties go to the candidate with the least induced cost, found first.)
+    const Node2 sb = nodes[sub];
+    const double sub_area = area[sub];
+    double best = DBL_MAX;
+    uint32_t best_x = root;
+    heap.clear();
+    heap.push_back({0.0, root});
+    while (!heap.empty()) {
+      std::pop_heap(heap.begin(), heap.end(), worse);
+      const Cand c = heap.back();
+      heap.pop_back();
+      if (c.induced + sub_area >= best) break;   // everything left in the heap has at least this much induced cost
+      const double direct = union_area(c.node, sb);
+      if (c.induced + direct < best) { best = c.induced + direct; best_x = c.node; }
+      if (c0[c.node] != NONE) {
+        const double ind = c.induced + direct - area[c.node];
+        if (ind + sub_area < best) {
+          heap.push_back({ind, c0[c.node]}); std::push_heap(heap.begin(), heap.end(), worse);
+          heap.push_back({ind, c1[c.node]}); std::push_heap(heap.begin(), heap.end(), worse);
+        }
+      }
+    }
+    link(q, best_x, sub);
+  };
+  std::vector<uint32_t> sel;
+  const bool verbose = getenv("PT_BVH_REINSERT_VERBOSE") != nullptr;
+  auto total_area = [&]() { double t = 0.0; for (uint32_t i = 0; i < n; ++i) if (c0[i] != NONE) t += area[i]; return t; };
+  const double area_before = total_area();
+  if (verbose) fprintf(stderr, "reinsertion: binary-tree area sum %.6g\n", area_before);
+  for (int pass = 0; pass < passes; ++pass) {
+    if (verbose && pass) fprintf(stderr, "reinsertion: after pass %d: %.6g\n", pass, total_area());
+    // a first pass that gains less than 1 % says the top-down tree is as good as this optimiser gets it (regular scenes:
+    // street -0.5 %, courtyard -0.1 %; atrium -3.3 %, street_hard -10.8 %): stop, build_bvh8 would discard the result anyway
+    if (pass == 1 && total_area() > 0.99 * area_before) return false;
+    sel.clear();
+    for (uint32_t i = 0; i < n; ++i)
+      if (c0[i] != NONE && i != root) sel.push_back(i);
+    size_t take = std::min<size_t>(max_per_pass, (size_t)((double)sel.size() * fraction));
+    if (take == 0) break;
+    take = std::min(take, sel.size());
+    // pass p works on the nodes ranked [p * take, (p + 1) * take) by area: the largest first, every node at most once
+    // (repeating the top slice converges after two or three passes and leaves the levels below untouched)
+    const size_t lo_rank = careful ? std::min((size_t)pass * take, sel.size() - take) : 0, hi_rank = lo_rank + take;
+    auto larger = [&](uint32_t a, uint32_t b) { return area[a] > area[b] || (area[a] == area[b] && a < b); };
+    if (hi_rank < sel.size()) std::nth_element(sel.begin(), sel.begin() + (ptrdiff_t)hi_rank, sel.end(), larger);
+    if (lo_rank > 0) std::nth_element(sel.begin(), sel.begin() + (ptrdiff_t)lo_rank, sel.begin() + (ptrdiff_t)hi_rank, larger);
+    std::sort(sel.begin() + (ptrdiff_t)lo_rank, sel.begin() + (ptrdiff_t)hi_rank, larger);
+    sel.erase(sel.begin(), sel.begin() + (ptrdiff_t)lo_rank);
+    for (size_t t = 0; t < take; ++t) {
+      const uint32_t N = sel[t];
+      if (N == root || c0[N] == NONE) continue;   // (ids are reused inside the pass)
+      // N and its parent P leave the tree (N's sibling S moves up), N's two subtrees go back one after the other, the larger
+      // first. Unlike putting N back as a whole this can END higher than it began (the second subtree finds the tree changed
+      // by the first): such an operation is undone — the tree is again what it was — so the area sum never grows.
+      const uint32_t P = parent[N], L = c0[N], R = c1[N];
+      const uint32_t S = c0[P] == N ? c1[P] : c0[P];
+      acc = -area[N];
+      unlink(P, S);
+      const bool l_first = area[L] >= area[R];
+      reinsert(l_first ? L : R, N);
+      reinsert(l_first ? R : L, P);
+      if (careful && acc > 0.0) {
+        const uint32_t a = l_first ? L : R, b = l_first ? R : L;   // a hangs under N, b under P
+        unlink(P, c0[P] == b ? c1[P] : c0[P]);
+        unlink(N, c0[N] == a ? c1[N] : c0[N]);
+        c0[N] = L; c1[N] = R; parent[L] = N; parent[R] = N;
+        Node2& nn_ = nodes[N];
+        for (int k = 0; k < 3; ++k) { nn_.lo[k] = std::min(nodes[L].lo[k], nodes[R].lo[k]); nn_.hi[k] = std::max(nodes[L].hi[k], nodes[R].hi[k]); }
+        area[N] = half_area(nn_.lo, nn_.hi);
+        parent[N] = NONE;
+        link(P, S, N);
+      }
+    }
+  }
+  if (verbose) fprintf(stderr, "reinsertion: after pass %d: %.6g\n", passes, total_area());
+  // back into the array form the collapse expects: root at 0, the two children of a node adjacent and after their parent
+  std::vector<Node2> out(n);
+  std::vector<uint32_t> old_of(n);
+  old_of[0] = root;
+  uint32_t next = 1;
+  for (uint32_t i = 0; i < n; ++i) {
+    const uint32_t o = old_of[i];
+    out[i] = nodes[o];
+    if (c0[o] != NONE) {
+      out[i].left = next;
+      old_of[next] = c0[o]; old_of[next + 1] = c1[o];
+      next += 2;
+    } else {
+      out[i].left = 0;
+    }
+  }
+  nodes.swap(out);
+  return true;
+}
+
 // Leaves of the binary tree hold one reference each (Node2::first = its primitive while building). This pass lays the
 // references out in depth-first order and gives every node the range of its subtree: first / count into `order`.
 static void assign_ranges(std::vector<Node2>& nodes, std::vector<uint32_t>& order) {
@@ -631,59 +812,116 @@ void build_bvh8(const float* verts, uint32_t n, Bvh8& out, int num_threads, int 
     sb.run(std::move(boxes), (uint64_t)((double)np * split_budget));
     out.spatial_splits = sb.spatial_splits();
   }
-  assign_ranges(n2, order);
-  out.num_references = order.size();
-  const uint32_t nn = (uint32_t)n2.size();
-
   // ---- SAH-optimal collapse (dynamic programme over "up to i roots", i = 1..7) ----
   // SAH constants of the collapse: cost of one 8-wide node step vs one triangle test. PT_BVH_CPRIM overrides the
   // triangle cost for tuning runs (tools/tune_bvh.sh).
   double Cnode = 1.0, Cprim = 0.3;
   if (const char* e = getenv("PT_BVH_CPRIM")) { const double v = atof(e); if (v > 0.0) Cprim = v; }
-  std::vector<double> cost((size_t)nn * 7);
-  std::vector<uint8_t> dec((size_t)nn * 7);
-  std::vector<uint8_t> isplit(nn, 0);
-  std::vector<float> wsum(nn, 0.0f);   // SAH weight of the records below a node (children are allocated after their parent)
-  for (uint32_t idx = nn; idx-- > 0;) {
-    const Node2& nd = n2[idx];
-    const double A = half_area(nd.lo, nd.hi);
-    double* c = &cost[(size_t)idx * 7];
-    uint8_t* d = &dec[(size_t)idx * 7];
-    if (nd.left == 0) {
-      for (uint32_t i = 0; i < nd.count; ++i) wsum[idx] += weight[order[nd.first + i]];
-      for (int i = 0; i < 7; ++i) { c[i] = A * Cprim * (double)wsum[idx]; d[i] = mk_dec(D_LEAF, 0, 0); }
-      continue;
-    }
-    wsum[idx] = wsum[nd.left] + wsum[nd.left + 1];
-    const double* cl = &cost[(size_t)nd.left * 7];
-    const double* cr = &cost[(size_t)(nd.left + 1) * 7];
-    double cdist[9]; int ksplit[9];
-    for (int j = 2; j <= 8; ++j) {
-      double best = DBL_MAX; int bk = 1;
-      for (int k = 1; k < j; ++k) {
-        if (k > 7 || j - k > 7) continue;
-        const double v = cl[k - 1] + cr[j - k - 1];
-        if (v < best) { best = v; bk = k; }
+  struct Collapse {
+    std::vector<uint32_t> order;
+    std::vector<double> cost;
+    std::vector<uint8_t> dec, isplit;
+  };
+  // lays the tree's references out (assign_ranges) and fills the decision tables; returns the SAH cost of the 8-wide tree
+  auto collapse = [&](std::vector<Node2>& tree, Collapse& cl) -> double {
+    assign_ranges(tree, cl.order);
+    const uint32_t nn = (uint32_t)tree.size();
+    cl.cost.assign((size_t)nn * 7, 0.0);
+    cl.dec.assign((size_t)nn * 7, 0);
+    cl.isplit.assign(nn, 0);
+    std::vector<float> wsum(nn, 0.0f);   // SAH weight of the records below a node (children are allocated after their parent)
+    for (uint32_t idx = nn; idx-- > 0;) {
+      const Node2& nd = tree[idx];
+      const double A = half_area(nd.lo, nd.hi);
+      double* c = &cl.cost[(size_t)idx * 7];
+      uint8_t* d = &cl.dec[(size_t)idx * 7];
+      if (nd.left == 0) {
+        for (uint32_t i = 0; i < nd.count; ++i) wsum[idx] += weight[cl.order[nd.first + i]];
+        for (int i = 0; i < 7; ++i) { c[i] = A * Cprim * (double)wsum[idx]; d[i] = mk_dec(D_LEAF, 0, 0); }
+        continue;
       }
-      cdist[j] = best; ksplit[j] = bk;
+      wsum[idx] = wsum[nd.left] + wsum[nd.left + 1];
+      const double* cl_ = &cl.cost[(size_t)nd.left * 7];
+      const double* cr = &cl.cost[(size_t)(nd.left + 1) * 7];
+      double cdist[9]; int ksplit[9];
+      for (int j = 2; j <= 8; ++j) {
+        double best = DBL_MAX; int bk = 1;
+        for (int k = 1; k < j; ++k) {
+          if (k > 7 || j - k > 7) continue;
+          const double v = cl_[k - 1] + cr[j - k - 1];
+          if (v < best) { best = v; bk = k; }
+        }
+        cdist[j] = best; ksplit[j] = bk;
+      }
+      const double cleaf = nd.count <= PT_BVH8_MAX_LEAF_TRIS ? A * Cprim * (double)wsum[idx] : DBL_MAX;
+      const double cint = cdist[8] + A * Cnode;
+      cl.isplit[idx] = (uint8_t)ksplit[8];
+      if (cleaf <= cint) { c[0] = cleaf; d[0] = mk_dec(D_LEAF, 0, 0); }
+      else { c[0] = cint; d[0] = mk_dec(D_INTERNAL, 0, 0); }
+      for (int i = 1; i < 7; ++i) {
+        if (cdist[i + 1] < c[i - 1]) { c[i] = cdist[i + 1]; d[i] = mk_dec(D_DISTRIBUTE, ksplit[i + 1], i + 1 - ksplit[i + 1]); }
+        else { c[i] = c[i - 1]; d[i] = d[i - 1]; }
+      }
     }
-    const double cleaf = nd.count <= PT_BVH8_MAX_LEAF_TRIS ? A * Cprim * (double)wsum[idx] : DBL_MAX;
-    const double cint = cdist[8] + A * Cnode;
-    isplit[idx] = (uint8_t)ksplit[8];
-    if (cleaf <= cint) { c[0] = cleaf; d[0] = mk_dec(D_LEAF, 0, 0); }
-    else { c[0] = cint; d[0] = mk_dec(D_INTERNAL, 0, 0); }
-    for (int i = 1; i < 7; ++i) {
-      if (cdist[i + 1] < c[i - 1]) { c[i] = cdist[i + 1]; d[i] = mk_dec(D_DISTRIBUTE, ksplit[i + 1], i + 1 - ksplit[i + 1]); }
-      else { c[i] = c[i - 1]; d[i] = d[i - 1]; }
+    return cl.cost[0];
+  };
+  // Insertion-based optimisation of the binary tree (optimize_by_reinsertion), kept only if the 8-wide tree that comes out of
+  // it is better by the collapse's own objective: the optimiser minimises the area of ALL binary nodes, the traversal pays
+  // for the ones the collapse keeps, and the two do not always move together. CPU walker, node visits per secondary ray
+  // (tools/bvh_cpu_quality.py), 5 passes over the 2 % largest nodes: atrium 13.88 -> 13.42 (8-wide SAH cost -3.9 %),
+  // street_hard 37.7 -> 35.4 (-9.8 %), courtyard 18.76 -> 18.67 (-0.4 %), street 14.11 -> 14.51 (+0.01 %): the last two keep
+  // the top-down tree. PT_BVH_REINSERT_PASSES / _FRAC / _CAP: tuning runs (0 passes = off).
+  int reinsert_passes = 5;
+  double reinsert_frac = 0.02;
+  size_t reinsert_cap = (size_t)1 << 20;
+  if (const char* e = getenv("PT_BVH_REINSERT_PASSES")) reinsert_passes = atoi(e);
+  if (const char* e = getenv("PT_BVH_REINSERT_FRAC")) { const double v = atof(e); if (v > 0.0 && v <= 1.0) reinsert_frac = v; }
+  if (const char* e = getenv("PT_BVH_REINSERT_CAP")) { const long v = atol(e); if (v > 0) reinsert_cap = (size_t)v; }
+  Collapse cl;
+  {
+    // the top-down tree and the two optimised copies: three collapses, the cheapest 8-wide tree wins (an optimised one has
+    // to be better by 1 %); the copies are worked on by two more threads when the caller gave any
+    std::vector<Node2> cand[2];
+    Collapse ccl[2];
+    double ccost[2] = {DBL_MAX, DBL_MAX};
+    const bool optimise = reinsert_passes > 0 && n2.size() >= 64;
+    auto work = [&](int v) {
+      cand[v] = n2;
+      if (optimize_by_reinsertion(cand[v], reinsert_passes, reinsert_frac, reinsert_cap, v == 1)) ccost[v] = collapse(cand[v], ccl[v]);
+      else std::vector<Node2>().swap(cand[v]);
+    };
+    std::vector<std::thread> pool;
+    if (optimise) {
+      if (num_threads > 1) { pool.emplace_back(work, 0); pool.emplace_back(work, 1); }
+      else { work(0); work(1); }
     }
+    double c = 0.0;
+    {
+      std::vector<Node2> keep;
+      if (optimise && num_threads > 1) keep = n2;   // the threads copy from n2 while it is collapsed: collapse a copy of our own
+      c = collapse(optimise && num_threads > 1 ? keep : n2, cl);
+      for (auto& th : pool) th.join();
+      if (optimise && num_threads > 1) n2.swap(keep);
+    }
+    const int v = ccost[1] < ccost[0] ? 1 : 0;
+    if (optimise && ccost[v] < 0.99 * c) {
+      n2.swap(cand[v]);
+      std::swap(cl, ccl[v]);
+      c = ccost[v];
+      out.reinsertion_kept = 1 + v;
+    }
+    out.sah_cost = c;
   }
-  out.sah_cost = (float)cost[0];
+  const std::vector<uint32_t>& ord = cl.order;   // references in depth-first order of the chosen tree
+  const std::vector<uint8_t>&dec = cl.dec, &isplit = cl.isplit;
+  out.num_references = ord.size();
+  const uint32_t nn = (uint32_t)n2.size();
 
   // ---- emit 8-wide nodes breadth-first ----
   struct Work { uint32_t n2; uint32_t out; uint32_t depth; };
   std::deque<Work> queue;
   out.nodes.reserve(nn / 4 + 16);
-  if (out.paired) out.prims.reserve(order.size()); else out.tris.reserve(order.size());
+  if (out.paired) out.prims.reserve(ord.size()); else out.tris.reserve(ord.size());
   out.nodes.emplace_back();
   queue.push_back({0, 0, 1});
   std::vector<ChildRef> kids;
@@ -799,7 +1037,7 @@ void build_bvh8(const float* verts, uint32_t n, Bvh8& out, int num_threads, int 
         // 1..3 references; two pieces of one primitive that a spatial split sent into the same leaf need one record only
         uint32_t uniq[PT_BVH8_MAX_LEAF_TRIS], cnt = 0;
         for (uint32_t i = 0; i < ch.count; ++i) {
-          const uint32_t pk = order[ch.first + i];
+          const uint32_t pk = ord[ch.first + i];
           bool seen = false;
           for (uint32_t j = 0; j < cnt; ++j) seen = seen || uniq[j] == pk;
           if (!seen) uniq[cnt++] = pk;

@@ -24,6 +24,7 @@ struct Bvh8 {
   double sah_cost = 0.0;
   uint64_t num_references = 0;     // leaf references of the binary tree: primitives + the duplicates spatial splits made
   uint64_t spatial_splits = 0;     // nodes of the binary tree that were split by a plane instead of by partitioning objects
+  int reinsertion_kept = 0;        // 0 = the top-down binary tree was collapsed as built; 1 / 2 = its insertion-optimised copy (form 1 / 2) gave the better 8-wide tree
 };
 
 // verts: 9 floats per triangle (v0,v1,v2 world space); triangle i gets global id i.

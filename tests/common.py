@@ -124,15 +124,19 @@ import contextlib
 
 @contextlib.contextmanager
 def object_splits_only():
-    """Scenes created inside are built WITHOUT spatial splits (PT_BVH_SPLIT_BUDGET=0, read by the builder at scene
-    creation): the tests of the deep-stack / spill paths need the degenerate, very deep hierarchy that spatial splits
-    would repair (depth 8 instead of > 24 on the nested-triangle scene)."""
-    old = os.environ.get("PT_BVH_SPLIT_BUDGET")
-    os.environ["PT_BVH_SPLIT_BUDGET"] = "0"
+    """Scenes created inside are built WITHOUT spatial splits and WITHOUT the insertion-based optimisation of the binary
+    tree (PT_BVH_SPLIT_BUDGET=0, PT_BVH_REINSERT_PASSES=0, read by the builder at scene creation): the tests of the
+    deep-stack / spill paths need the degenerate, very deep hierarchy that either would repair (depth 8 instead of > 24 on
+    the nested-triangle scene)."""
+    names = ("PT_BVH_SPLIT_BUDGET", "PT_BVH_REINSERT_PASSES")
+    old = {k: os.environ.get(k) for k in names}
+    for k in names:
+        os.environ[k] = "0"
     try:
         yield
     finally:
-        if old is None:
-            del os.environ["PT_BVH_SPLIT_BUDGET"]
-        else:
-            os.environ["PT_BVH_SPLIT_BUDGET"] = old
+        for k in names:
+            if old[k] is None:
+                del os.environ[k]
+            else:
+                os.environ[k] = old[k]

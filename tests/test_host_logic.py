@@ -415,6 +415,63 @@ def test_bvh8_builder_both_leaf_formats_walk_to_the_oracle_hits(oracle, scene):
         assert 1 <= stats[1][2] <= 8                              # a random soup shares no edges; the duplicates do
 
 
+def test_insertion_based_tree_optimisation_keeps_hits_and_pays_on_clutter(oracle):
+    """csrc/bvh_builder.cpp optimises the finished binary tree by taking its largest nodes out and putting their subtrees back
+    where they add the least area (two forms), and keeps the result only if the 8-wide tree it collapses to is better by the
+    collapse's own SAH cost. Hit records cannot depend on it; on overlapping, randomly rotated clutter (what a top-down
+    builder is worst at) it must lower both that cost and the node visits of incoherent rays."""
+    so = os.path.join(ROOT, "tests", "walker", "libbvh8_walker.so")
+    wl = C.CDLL(so)
+    P = C.c_void_p
+    wl.bvh8_build.restype = P
+    wl.bvh8_build.argtypes = [P, C.c_uint32, C.c_int, C.c_int, P]
+    wl.bvh8_free.argtypes = [P]
+    wl.bvh8_walk_built.restype = C.c_int
+    wl.bvh8_walk_built.argtypes = [P, P, C.c_uint64, P, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_int]
+    rng = np.random.default_rng(12)
+    # 600 long thin boxes (beams) with random orientations through one another, 12 triangles each
+    tris = []
+    corners = np.array([[x, y, z] for x in (-1, 1) for y in (-1, 1) for z in (-1, 1)], dtype=np.float64)
+    faces = [(0, 1, 3), (0, 3, 2), (4, 6, 7), (4, 7, 5), (0, 4, 5), (0, 5, 1), (2, 3, 7), (2, 7, 6), (0, 2, 6), (0, 6, 4), (1, 5, 7), (1, 7, 3)]
+    for _ in range(600):
+        q, _r = np.linalg.qr(rng.normal(size=(3, 3)))
+        c = (corners * np.array([rng.uniform(2, 9), 0.08, 0.12])) @ q.T + rng.uniform(-10, 10, size=3)
+        tris += [np.concatenate([c[a], c[b], c[d]]) for a, b, d in faces]
+    tris = np.ascontiguousarray(np.array(tris), dtype=np.float32)
+    from tests.common import random_rays
+    rays = random_rays(3, 40000, (-12, -12, -12), (12, 12, 12), tmin=0.001, tmax=1e4)
+
+    def build_and_walk(passes):
+        old = os.environ.get("PT_BVH_REINSERT_PASSES")
+        if passes is None:
+            os.environ.pop("PT_BVH_REINSERT_PASSES", None)
+        else:
+            os.environ["PT_BVH_REINSERT_PASSES"] = str(passes)
+        try:
+            info = (C.c_uint64 * 8)()
+            h = wl.bvh8_build(api.ptr(tris), len(tris), 0, 4, info)
+        finally:
+            if old is None:
+                os.environ.pop("PT_BVH_REINSERT_PASSES", None)
+            else:
+                os.environ["PT_BVH_REINSERT_PASSES"] = old
+        hits = np.empty(len(rays), dtype=api.HIT_DTYPE)
+        cn, ct = C.c_uint64(), C.c_uint64()
+        assert wl.bvh8_walk_built(h, api.ptr(rays), len(rays), api.ptr(hits), C.byref(cn), C.byref(ct), 4) == 0
+        wl.bvh8_free(h)
+        sah = float(np.array([info[6]], dtype=np.uint64).view(np.float64)[0])
+        return hits, cn.value, ct.value, sah
+    h0, n0, t0, s0 = build_and_walk(0)
+    h1, n1, t1, s1 = build_and_walk(None)        # the shipped default
+    h2, n2, t2, s2 = build_and_walk(None)        # and again: the build is deterministic
+    assert np.array_equal(h0.view(np.uint32), h1.view(np.uint32))
+    assert (h0["prim"] != api.PT_MISS).mean() > 0.2
+    assert (n1, t1, s1) == (n2, t2, s2) and np.array_equal(h1.view(np.uint32), h2.view(np.uint32))
+    assert s1 < 0.99 * s0, (s0, s1)              # kept only when better by 1 % ...
+    assert n1 < 0.97 * n0, (n0, n1)              # ... and the rays agree
+    assert 80 * n1 + 48 * t1 < 80 * n0 + 48 * t0
+
+
 def test_roofline_pmc_entry_is_tied_to_the_build(tmp_path, monkeypatch):
     """bench.py prices k_extend's launch time against committed PMC counters only when they were measured on THIS build of
     the kernels: every entry of profiles/<round>/pmc_traffic.json carries the fingerprint of the sources it ran on."""

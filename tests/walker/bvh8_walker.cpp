@@ -189,6 +189,7 @@ extern "C" void* bvh8_build(const float* verts, uint32_t num_tris, int pair_mode
   pt::build_bvh8(verts, num_tris, *b, threads, pair_mode);
   info[0] = b->nodes.size(); info[1] = b->num_records(); info[2] = b->num_pairs; info[3] = b->record_bytes(); info[4] = b->max_depth;
   info[5] = (uint64_t)b->build_ms;
+  { const double c = (double)b->sah_cost; memcpy(&info[6], &c, 8); }   // SAH cost of the 8-wide tree (the collapse's objective)
   return b;
 }
 extern "C" void bvh8_free(void* h) { delete static_cast<pt::Bvh8*>(h); }

@@ -92,8 +92,9 @@ def measure(name, pair_mode=-1, w=320, h=180, bounces=3, threads=8, quiet=False)
     hnd = wl.bvh8_build(api.ptr(tris), len(tris), pair_mode, threads, info)
     build_s = time.time() - t0
     nn, nr, npairs, rb, depth = (int(info[k]) for k in range(5))
+    sah = float(np.array([info[6]], dtype=np.uint64).view(np.float64)[0])
     res = {"workload": name, "triangles": len(tris), "nodes": nn, "records": nr, "pairs": npairs, "record_bytes": rb, "depth": depth,
-           "bvh_mb": (nn * 80 + nr * rb) / 1e6, "build_s": build_s, "bounce": []}
+           "bvh_mb": (nn * 80 + nr * rb) / 1e6, "build_s": build_s, "sah_cost": sah, "bounce": []}
     rng = np.random.default_rng(7)
     rays = primary_rays(lookat_consts(w, h, cam), w, h)
     for b in range(bounces + 1):
@@ -113,7 +114,7 @@ def measure(name, pair_mode=-1, w=320, h=180, bounces=3, threads=8, quiet=False)
     tot = sum(b["rays"] for b in sec) or 1
     res["secondary"] = {k: sum(b[k] * b["rays"] for b in sec) / tot for k in ("nodes_per_ray", "tris_per_ray", "bytes_per_ray")}
     if not quiet:
-        print(f"{name}: {len(tris)} tris, {nn} nodes, {nr} records x {rb} B ({npairs} pairs), {res['bvh_mb']:.1f} MB, depth {depth}, build {build_s:.1f} s")
+        print(f"{name}: {len(tris)} tris, {nn} nodes, {nr} records x {rb} B ({npairs} pairs), {res['bvh_mb']:.1f} MB, depth {depth}, build {build_s:.1f} s, SAH cost of the 8-wide tree {sah:.6g}")
         for b, r in enumerate(res["bounce"]):
             print(f"  bounce {b}: {r['rays']:7d} rays  {r['nodes_per_ray']:6.2f} nodes + {r['tris_per_ray']:6.2f} tris per ray = {r['bytes_per_ray']:7.1f} B/ray  hit {r['hit_rate']:.3f} crc {r['hits_crc']:x}")
         s = res["secondary"]
