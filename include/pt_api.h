@@ -138,7 +138,11 @@ enum {
      48-byte single-triangle records below that (pairs cost 4 % there). These flags force one or the other; hit records
      are identical either way. */
   PT_SCENE_PAIR_TRIANGLES = 2,
-  PT_SCENE_NO_PAIRS = 4
+  PT_SCENE_NO_PAIRS = 4,
+  /* Build quickly rather than well: no spatial splits and no optimisation pass over the tree (a third of the build time;
+     traversal is a few per cent slower on regular scenes and several times slower on long thin or overlapping geometry).
+     For interactive loading; hit records are identical either way. */
+  PT_SCENE_FAST_BUILD = 8
 };
 
 /* closest-hit record returned by the trace entry points */

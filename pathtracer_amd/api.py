@@ -29,6 +29,7 @@ PT_SCENE_DEFAULT = 0
 PT_SCENE_TRANSFORM_NORMALS = 1
 PT_SCENE_PAIR_TRIANGLES = 2
 PT_SCENE_NO_PAIRS = 4
+PT_SCENE_FAST_BUILD = 8
 
 PT_OPT_COUNT_TRAVERSAL = 1
 PT_OPT_TIME_KERNELS = 2

@@ -516,6 +516,8 @@ static bool optimize_by_reinsertion(std::vector<Node2>& nodes, int passes, doubl
     for (int k = 0; k < 3; ++k) { lo[k] = std::min(a.lo[k], s.lo[k]); hi[k] = std::max(a.hi[k], s.hi[k]); }
     return half_area(lo, hi);
   };
+  constexpr uint32_t kMaxSearchSteps = 2048;   // per insertion: 45 on average, 172 at most on the scenes measured
+  uint32_t max_pops = 0; uint64_t sum_pops = 0, n_searches = 0;
   struct Cand { double induced; uint32_t node; };
   auto worse = [](const Cand& a, const Cand& b) { return a.induced > b.induced || (a.induced == b.induced && a.node > b.node); };
   std::vector<Cand> heap;
@@ -529,7 +531,9 @@ static bool optimize_by_reinsertion(std::vector<Node2>& nodes, int passes, doubl
     uint32_t best_x = root;
     heap.clear();
     heap.push_back({0.0, root});
+    uint32_t pops = 0;
     while (!heap.empty()) {
+      if (++pops > kMaxSearchSteps) break;   // bounds the build time on a pathological tree; the best place found so far is still a valid one
       std::pop_heap(heap.begin(), heap.end(), worse);
       const Cand c = heap.back();
       heap.pop_back();
@@ -544,6 +548,7 @@ static bool optimize_by_reinsertion(std::vector<Node2>& nodes, int passes, doubl
         }
       }
     }
+    max_pops = std::max(max_pops, pops); sum_pops += pops; ++n_searches;
     link(q, best_x, sub);
   };
   std::vector<uint32_t> sel;
@@ -596,7 +601,8 @@ static bool optimize_by_reinsertion(std::vector<Node2>& nodes, int passes, doubl
       }
     }
   }
-  if (verbose) fprintf(stderr, "reinsertion: after pass %d: %.6g\n", passes, total_area());
+  if (verbose) fprintf(stderr, "reinsertion: after pass %d: %.6g; %llu searches, %.1f steps on average, %u at most\n", passes, total_area(),
+                       (unsigned long long)n_searches, (double)sum_pops / (double)std::max<uint64_t>(1, n_searches), max_pops);
   // back into the array form the collapse expects: root at 0, the two children of a node adjacent and after their parent
   std::vector<Node2> out(n);
   std::vector<uint32_t> old_of(n);
@@ -720,7 +726,7 @@ static void pair_triangles(const float* verts, const std::vector<uint32_t>& acti
 
 }  // namespace
 
-void build_bvh8(const float* verts, uint32_t n, Bvh8& out, int num_threads, int pair_mode) {
+void build_bvh8(const float* verts, uint32_t n, Bvh8& out, int num_threads, int pair_mode, bool fast) {
   auto t0 = std::chrono::steady_clock::now();
   if (num_threads <= 0) {
     num_threads = (int)std::thread::hardware_concurrency();
@@ -806,6 +812,7 @@ void build_bvh8(const float* verts, uint32_t n, Bvh8& out, int num_threads, int 
   if (const char* e = getenv("PT_BVH_SPLIT_BUDGET")) { const double v = atof(e); if (v >= 0.0 && v <= 4.0) split_budget = v; }
   if (const char* e = getenv("PT_BVH_SPLIT_ALPHA")) { const double v = atof(e); if (v >= 0.0) split_alpha = v; }
   if (const char* e = getenv("PT_BVH_SPLIT_GAIN")) { const double v = atof(e); if (v > 0.0) split_gain = v; }
+  if (fast) split_budget = 0.0;
   std::vector<Node2> n2;
   {
     SplitBuilder sb(verts, refs, pad, n2, num_threads, split_alpha, split_gain);
@@ -877,6 +884,7 @@ void build_bvh8(const float* verts, uint32_t n, Bvh8& out, int num_threads, int 
   if (const char* e = getenv("PT_BVH_REINSERT_PASSES")) reinsert_passes = atoi(e);
   if (const char* e = getenv("PT_BVH_REINSERT_FRAC")) { const double v = atof(e); if (v > 0.0 && v <= 1.0) reinsert_frac = v; }
   if (const char* e = getenv("PT_BVH_REINSERT_CAP")) { const long v = atol(e); if (v > 0) reinsert_cap = (size_t)v; }
+  if (fast) reinsert_passes = 0;
   Collapse cl;
   {
     // the top-down tree and the two optimised copies: three collapses, the cheapest 8-wide tree wins (an optimised one has

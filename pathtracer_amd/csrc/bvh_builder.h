@@ -30,10 +30,12 @@ struct Bvh8 {
 // verts: 9 floats per triangle (v0,v1,v2 world space); triangle i gets global id i.
 // Edge-sharing triangles are paired into primitives first (greedy, by exact vertex positions). Binned-SAH binary BVH
 // with spatial splits (SBVH: a long or diagonal primitive may be referenced from several leaves, each with the tight box
-// of its piece; single-reference leaves) -> SAH-optimal collapse to 8-wide nodes with <=3 records per
+// of its piece; single-reference leaves) -> insertion-based optimisation of that tree, kept when the 8-wide tree gets
+// better -> SAH-optimal collapse to 8-wide nodes with <=3 records per
 // leaf -> octant-ordered child slots -> 8-bit quantisation (conservative, padded by a scene-relative epsilon).
 // pair_mode: 0 = triangle records, 1 = pair edge-sharing triangles, -1 = decide by size (pairs once the unpaired hierarchy
 // would exceed the Infinity Cache: measured +9.5 % on 10.5 M triangles, -4 % on 262 k).
-void build_bvh8(const float* verts, uint32_t num_tris, Bvh8& out, int num_threads = 0, int pair_mode = -1);
+// fast: no spatial splits and no insertion-based optimisation of the binary tree (PT_SCENE_FAST_BUILD).
+void build_bvh8(const float* verts, uint32_t num_tris, Bvh8& out, int num_threads = 0, int pair_mode = -1, bool fast = false);
 
 }  // namespace pt

@@ -197,6 +197,7 @@ __global__ void k_primary_setup(PtRtConsts c, float4* __restrict__ gen, uint32_t
 #ifndef PT_SHARED_TAKE
 #define PT_SHARED_TAKE 4u    // records a lane offers per pass (64 x PT_SHARED_TAKE <= PT_SHARED_LIST)
 #endif
+static_assert(64u * PT_SHARED_TAKE <= PT_SHARED_LIST, "a pass of the shared triangle phase lists up to PT_SHARED_TAKE records per lane");
 #ifndef PT_EXTEND_NODE_STEPS
 #define PT_EXTEND_NODE_STEPS 3   // box tests per scheduler iteration of the deferred schedule (1..4; C2 extend: 6.79, 6.95, 6.98, 6.83 Grays/s)
 #endif

@@ -650,7 +650,8 @@ int pt_scene_create(pt_ctx* ctx, const PtMeshDesc* meshes, uint32_t num_meshes, 
   int rc = flatten_scene(meshes, num_meshes, instances, num_instances, materials, num_materials, flags, fs, err);
   if (rc != PT_OK) return ctx->fail(rc, err);
   Bvh8 bvh;
-  build_bvh8(fs.tri_verts.data(), fs.num_triangles(), bvh, 0, (flags & PT_SCENE_PAIR_TRIANGLES) ? 1 : ((flags & PT_SCENE_NO_PAIRS) ? 0 : -1));
+  build_bvh8(fs.tri_verts.data(), fs.num_triangles(), bvh, 0, (flags & PT_SCENE_PAIR_TRIANGLES) ? 1 : ((flags & PT_SCENE_NO_PAIRS) ? 0 : -1),
+             (flags & PT_SCENE_FAST_BUILD) != 0);
 
   // the traversal kernel addresses nodes and triangle records with 32-bit byte offsets
   if (bvh.nodes.size() * (size_t)(PT_NODE_STRIDE_U4 * 16) >= (1ull << 32) || bvh.num_records() * bvh.record_bytes() >= (1ull << 32))

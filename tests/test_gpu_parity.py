@@ -860,6 +860,26 @@ def test_extend_schedule_options_never_change_hits(ctx, oracle, fetch_min, postp
     assert np.array_equal(occ.astype(bool), hit)
 
 
+def test_fast_build_flag_gives_the_same_hits_with_a_plainer_tree(ctx, oracle):
+    """PT_SCENE_FAST_BUILD skips the spatial splits and the optimisation pass over the binary tree: no reference is duplicated,
+    the build is quicker, the hit records are the same bits (they never depend on the acceleration structure)."""
+    sc = scenes.random_triangle_soup(11, 60000)
+    rays = None
+    got = {}
+    for flags in (api.PT_SCENE_NO_PAIRS, api.PT_SCENE_NO_PAIRS | api.PT_SCENE_FAST_BUILD):
+        ctx.scene_create(sc, flags)
+        info = ctx.scene_info()
+        if rays is None:
+            rays = random_rays(5, 100000, list(info.bounds_min), list(info.bounds_max), tmin=0.001, tmax=10000.0)
+        _, tris, _ = ctx.debug_read_bvh()
+        got[flags] = (ctx.trace_rays(rays), len(tris), info.build_ms)
+    full, fast = got[api.PT_SCENE_NO_PAIRS], got[api.PT_SCENE_NO_PAIRS | api.PT_SCENE_FAST_BUILD]
+    assert np.array_equal(full[0].view(np.uint32), fast[0].view(np.uint32))
+    ref = oracle.scene(sc).trace_rays(rays)
+    assert np.array_equal(fast[0]["prim"], ref["prim"])
+    assert fast[1] == 60000 and full[1] >= 60000     # one record per triangle without spatial splits
+
+
 @pytest.mark.parametrize("pairs", [False, True], ids=["48-byte-triangles", "64-byte-pairs"])
 def test_shared_triangle_phase_gives_the_same_hit_records(ctx, oracle, pairs):
     """PT_OPT_SHARED_TRIANGLE_PHASE = 1: the wave pools the pending leaf records of its 64 rays and tests them 64 at a time; a
