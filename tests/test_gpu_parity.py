@@ -518,6 +518,16 @@ def test_street_hard_sah_hostile_scene_hits_and_image_match_oracle(ctx, oracle):
     assert 0.2 < hit.mean() < 1.0
     for f in ("t", "u", "v"):
         assert np.array_equal(got[f][hit].view(np.uint32), ref[f][hit].view(np.uint32)), f
+    # this is the scene the library runs its shared triangle phase on (PT_OPT_SHARED_TRIANGLE_PHASE = 2 picks it here):
+    # forced on, the same rays give the same bits, the many duplicated references included
+    try:
+        ctx.set_option(api.PT_OPT_SHARED_TRIANGLE_PHASE, 1)
+        ctx.stats_reset()
+        got_shared = ctx.trace_rays(rays)
+        assert ctx.stats().shared_launches > 0
+    finally:
+        ctx.set_option(api.PT_OPT_SHARED_TRIANGLE_PHASE, 2)
+    assert np.array_equal(got_shared.view(np.uint32), got.view(np.uint32))
     atm = oracle.earth_atmosphere()
     ctx.sky_set(atm)
     olut = oracle.transmittance_lut(atm)
