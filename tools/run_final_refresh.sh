@@ -28,6 +28,20 @@ pmc_one atrium 1920 1080 64 4 "" --workload atrium
 pmc_one street 1920 1080 64 8 "" --workload street
 pmc_one street_hard 1920 1080 64 8 "" --workload street_hard
 pmc_one courtyard 3840 2160 16 16 russian_roulette=1 --workload courtyard --width 3840 --height 2160 --spp-per-step 16 --russian-roulette 1
+if [ "${PMC_VARIANTS:-1}" = 1 ]; then   # the variants the bench also reports: C4 with the GGX extension, C5 without Russian roulette
+  mv gpurun_out/pmc_${TAG}_street gpurun_out/pmc_${TAG}_street_plain; mv gpurun_out/pmc_${TAG}_courtyard gpurun_out/pmc_${TAG}_courtyard_rr
+  pmc_one street 1920 1080 64 8 material_ext=1 --workload street --material-ext 1
+  mv gpurun_out/pmc_${TAG}_street_summary.txt gpurun_out/pmc_${TAG}_street_ggx_summary.txt
+  pmc_one courtyard 3840 2160 16 16 "" --workload courtyard --width 3840 --height 2160 --spp-per-step 16
+  mv gpurun_out/pmc_${TAG}_courtyard_summary.txt gpurun_out/pmc_${TAG}_courtyard_no_rr_summary.txt
+fi
+# per-kernel time of the other workloads (the headline's trace is above)
+for w in street street_hard courtyard; do
+  extra=""; [ $w = courtyard ] && extra="--width 3840 --height 2160 --spp-per-step 16 --russian-roulette 1"
+  mkdir -p gpurun_out/${TAG}_trace_$w
+  timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${TAG}_trace_$w -- python3 bench.py --workload $w $extra --no-cpu-baseline --no-configs --no-roofline --steps 4 --warmup 1 > gpurun_out/${TAG}_trace_$w/bench.json 2> gpurun_out/${TAG}_trace_$w/bench.err || { echo "trace $w failed"; exit 1; }
+  python3 tools/kstats.py gpurun_out/${TAG}_trace_$w > gpurun_out/kernel_stats_${TAG}_$w.txt
+done
 cp profiles/$TAG/pmc_traffic.json gpurun_out/pmc_traffic_${TAG}.json
 echo "pmc ok"
 # (SKIP_ROUND=1: the bench lines run in a call of their own, after pmc_traffic.json has been copied into profiles/<round>/)
