@@ -257,7 +257,7 @@ def measure_extend(pt, ctx, api, step, W, H, SPP, depth, sample0, steps, leg):
         "triangle_phase": {"option": leg.get("shared_triangle_phase", 2), "choice": int(se.shared_choice), "shared_used": shared_used,
                            "timed_ms_per_lane": round(se.shared_cal_ms[0], 4), "timed_ms_shared": round(se.shared_cal_ms[1], 4),
                            "note": "PT_OPT_SHARED_TRIANGLE_PHASE: the wave pools its rays' pending leaf records and tests them 64 at a time; "
-                                   "option 2 times both forms on the warm-up step's bounce-1 queue and keeps the shared one if it wins by 2 %"},
+                                   "option 2 times both forms on a secondary-bounce queue of the warm-up step and keeps the shared one if it wins by 1 %"},
         "bytes_per_launch": round(alg_bytes, 1),
         "extend_share_of_render": round(se.extend_ms / max(se.render_ms, 1e-9), 4),
         "extend_mrays_per_s": round(se.rays / max(ext_s, 1e-12) / 1e6, 2),

@@ -10,6 +10,7 @@
 //   resolve  : NaN/Inf scrub + accumulation in sample order          (PathTracing.hlsl:130-137)
 // No kernel needs a host round trip: queue lengths live in device counters and the extend/shade/sky kernels are
 // persistent / grid-stride loops over them.
+#include <type_traits>
 #include "kernels.h"
 
 #include "shading_device.h"
@@ -198,6 +199,9 @@ __global__ void k_primary_setup(PtRtConsts c, float4* __restrict__ gen, uint32_t
 #define PT_SHARED_TAKE 4u    // records a lane offers per pass (64 x PT_SHARED_TAKE <= PT_SHARED_LIST)
 #endif
 static_assert(64u * PT_SHARED_TAKE <= PT_SHARED_LIST, "a pass of the shared triangle phase lists up to PT_SHARED_TAKE records per lane");
+#ifndef PT_EXTEND_COMPACT_ADDR
+#define PT_EXTEND_COMPACT_ADDR(PAIRS, SHARED) ((PAIRS) && (SHARED))   // which instantiations rebuild their stack / queue addresses at every access (extend_kernel.inc)
+#endif
 #ifndef PT_EXTEND_NODE_STEPS
 #define PT_EXTEND_NODE_STEPS 3   // box tests per scheduler iteration of the deferred schedule (1..4; C2 extend: 6.79, 6.95, 6.98, 6.83 Grays/s)
 #endif
@@ -352,14 +356,14 @@ __global__ void __launch_bounds__(256) k_extend_packet(const uint4* __restrict__
       const bool wave_risky = __ballot(tr.risky) != 0ull;
       // traversal order and the bit positions of the hit mask: the octant of the wave's first ray, for every lane (the
       // near / far planes of the slab test stay each lane's own)
-      const uint32_t oct = (uint32_t)__builtin_amdgcn_readfirstlane((int)tr.oct);
+      const uint32_t oct = (uint32_t)__builtin_amdgcn_readfirstlane((int)tr.oct());
       const uint32_t oct4 = oct * 0x01010101u;
       const bool negx = tr.idx < 0.0f, negy = tr.idy < 0.0f, negz = tr.idz < 0.0f;
       // coherent wave: every lane in the first ray's octant, with the same dominant axis and winding of the triangle test,
       // and no lane on the overflow-safe box test; then the per-node and per-triangle selections below are scalar
       const bool wnegx = (oct & 1u) != 0u, wnegy = (oct & 2u) != 0u, wnegz = (oct & 4u) != 0u;
       const int wkx = __builtin_amdgcn_readfirstlane(tr.tt.kx), wky = __builtin_amdgcn_readfirstlane(tr.tt.ky), wkz = __builtin_amdgcn_readfirstlane(tr.tt.kz);
-      const bool coherent = !wave_risky && __ballot(tr.oct != oct || tr.tt.kx != wkx || tr.tt.ky != wky || tr.tt.kz != wkz) == 0ull;
+      const bool coherent = !wave_risky && __ballot(tr.oct() != oct || tr.tt.kx != wkx || tr.tt.ky != wky || tr.tt.kz != wkz) == 0ull;
       // the ray origin in the triangle test's axis order (coherent waves: the same permutation for every lane)
       const float okx = sel3(tr.tt.ox, tr.tt.oy, tr.tt.oz, wkx), oky = sel3(tr.tt.ox, tr.tt.oy, tr.tt.oz, wky), okz = sel3(tr.tt.ox, tr.tt.oy, tr.tt.oz, wkz);
       // where the octant's near / far plane dwords sit among the node's six plane pairs (lo x, y, z, hi x, y, z): the

@@ -101,7 +101,7 @@ struct pt_ctx {
   float packet_cal_ms[2] = {0.0f, 0.0f};   // what it measured: k_extend, k_extend_packet
   uint64_t packet_launches = 0;
   // PT_OPT_SHARED_TRIANGLE_PHASE: 0 = per-lane triangle tests, 1 = shared triangle phase (kernels.hip), 2 = whichever traces
-  // this scene's secondary rays faster: the first large batch of a scene runs its bounce-1 queue twice more under HIP
+  // this scene's secondary rays faster: the first large batch of a scene runs its bounce-2 queue (bounce 1 at depth 1) twice more under HIP
   // events (same hit records every time), and the next call reads them. Until then: per-lane.
   int shared_tri = 2;
   int shared_choice = -1;             // -1 = not timed yet
@@ -344,7 +344,7 @@ bool use_shared_tri(const pt_ctx* ctx) {
 }
 
 // Reads the two timings of calibrate_shared_tri once they are there (blocks only if that batch is still running). The shared
-// phase must win by 2 %: within the timing noise the per-lane kernel is kept, so the choice is reproducible from run to run.
+// phase must win by 1 % (scenes it does not suit lose by 3-5 %): within the timing noise the per-lane kernel is kept, so the choice is reproducible from run to run.
 int resolve_shared_cal(pt_ctx* ctx) {
   if (!ctx->shared_cal_pending) return PT_OK;
   ctx->shared_cal_pending = false;
@@ -356,7 +356,7 @@ int resolve_shared_cal(pt_ctx* ctx) {
     ctx->shared_cal_ev[i] = {nullptr, nullptr};
   }
   if (ctx->shared_cal_ms[0] < 0.2f) return PT_OK;   // a near-empty queue says nothing: time a later batch
-  ctx->shared_choice = ctx->shared_cal_ms[1] <= 0.98f * ctx->shared_cal_ms[0] ? 1 : 0;
+  ctx->shared_choice = ctx->shared_cal_ms[1] <= 0.99f * ctx->shared_cal_ms[0] ? 1 : 0;
   return PT_OK;
 }
 
@@ -444,7 +444,7 @@ int calibrate_primary_kernel(pt_ctx* ctx, const PtRtConsts& consts, uint32_t wid
   return PT_OK;
 }
 
-// PT_OPT_SHARED_TRIANGLE_PHASE = 2: the bounce-1 queue of a batch (incoherent rays, already traced once by the caller: caches
+// PT_OPT_SHARED_TRIANGLE_PHASE = 2: one secondary-bounce queue of a batch (incoherent rays, already traced once by the caller: caches
 // warm, hit records in place) is traced again by the shared-phase instantiation and then by the per-lane one, each under a
 // pair of events. Every run writes the same hit records, so the render goes on unchanged; nothing waits here.
 int calibrate_shared_tri(pt_ctx* ctx, WavefrontBuffers& wb, uint32_t bounce) {
@@ -1054,7 +1054,7 @@ int pt_render(pt_ctx* ctx, const PtRtConsts* consts, uint32_t width, uint32_t he
         WavefrontBuffers& wb = *wbs[l];
         extend_one(ctx, wb.ray_o[in], wb.ray_d[in], 1, wb.hits, wb.counters + CTR_AT(CTR_QCOUNT0 + b), wb.counters + CTR_AT(CTR_WORK0 + b), (int)b, false, l,
                    (fused && b == 0) ? wb.gen : nullptr, /*packet=*/packet && b == 0);
-        if (calibrate_shared && b == 1 && l == 0) {
+        if (calibrate_shared && b == (bounces >= 3 ? 2u : 1u) && l == 0) {   // the second bounce when there is one: rays as incoherent as they get
           calibrate_shared = false;
           if ((rc = calibrate_shared_tri(ctx, wb, b)) != PT_OK) return rc;
         }

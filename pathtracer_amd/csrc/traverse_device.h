@@ -153,6 +153,35 @@ struct LaneStack {
     return make_uint2(w.x, w.y);
   }
 };
+// The same stack with its addresses rebuilt at every access from wave-uniform bases (scalar registers) and an opaque copy
+// of the lane id, instead of three per-lane address registers that live through the whole kernel: two or three more
+// instructions per push / pop, three registers fewer at the kernel's pressure peak (the box tests). For the instantiation
+// that needs them (pair records + shared triangle phase: with LaneStack it reloads spilled addresses in every node step).
+struct LaneStackCompact {
+  lds_u2* lds_wave;     // wave-uniform: lane 0's slot of LDS entry 0
+  glb_u2* spill_wave;   // wave-uniform: lane 0's slot of spill entry 0
+  uint32_t lane;
+  int lds_entries;
+  __device__ __forceinline__ uint32_t lane_here() const {
+    uint32_t l = lane;
+    asm volatile("" : "+v"(l));   // opaque: the address arithmetic stays at the access
+    return l;
+  }
+  __device__ __forceinline__ void put(int sp, uint2 v) const {
+    pt_u2v w;
+    w.x = v.x; w.y = v.y;
+    const uint32_t l = lane_here();
+    if (sp < lds_entries) lds_wave[(uint32_t)sp * 64u + l] = w;
+    else spill_wave[(uint32_t)(sp - lds_entries) * 64u + l] = w;
+  }
+  __device__ __forceinline__ uint2 get(int sp) const {
+    pt_u2v w;
+    const uint32_t l = lane_here();
+    if (sp < lds_entries) w = lds_wave[(uint32_t)sp * 64u + l];
+    else w = spill_wave[(uint32_t)(sp - lds_entries) * 64u + l];
+    return make_uint2(w.x, w.y);
+  }
+};
 
 // Per-lane traversal state of one ray. The wave-level loop that drives it (replenishing finished lanes, postponing
 // sparse triangle work) lives in k_extend; this struct holds what one lane carries between loop iterations.
@@ -161,8 +190,8 @@ struct Traverser {
   TriTester tt;
   HitRec best;
   float idx, idy, idz;
-  uint32_t oct;       // bit a set <=> direction component a is negative
-  uint32_t oct4;      // oct replicated into the four bytes of a dword
+  uint32_t oct4;      // the octant (bit a set <=> direction component a is negative) replicated into the four bytes of a dword
+  __device__ __forceinline__ uint32_t oct() const { return oct4 & 7u; }   // one full-rate AND where it is needed, not a register held through the kernel
   uint2 ng;           // pending node group: x = child_base, y = hit bits (top 8, by octant priority) | imask
   uint2 tg;           // pending triangle group: x = tri_base, y = triangle bits (low 24)
   int sp;
@@ -174,8 +203,7 @@ struct Traverser {
     tt.init(r);
     const float sdx = safe_dir(r.dx), sdy = safe_dir(r.dy), sdz = safe_dir(r.dz);
     idx = 1.0f / sdx; idy = 1.0f / sdy; idz = 1.0f / sdz;
-    oct = (sdx < 0.0f ? 1u : 0u) | (sdy < 0.0f ? 2u : 0u) | (sdz < 0.0f ? 4u : 0u);
-    oct4 = oct * 0x01010101u;
+    oct4 = ((sdx < 0.0f ? 1u : 0u) | (sdy < 0.0f ? 2u : 0u) | (sdz < 0.0f ? 4u : 0u)) * 0x01010101u;
     ng = make_uint2(0u, 0x80000000u);  // root: one pending internal "child" at priority 7 of a group with base 0
     tg = make_uint2(0u, 0u);
     sp = 0;
@@ -309,13 +337,14 @@ struct Traverser {
   // wave_risky (wave-uniform): some lane of the wave holds a ray flagged `risky` (refreshed at every refill).
   // top / top_nodes: the first top_nodes nodes of the array (its breadth-first top levels) also sit in LDS; lanes whose
   // node is among them read it there and stay off the vector-memory pipe.
-  __device__ __forceinline__ void node_step(const uint4* __restrict__ nodes, const LaneStack& stk, bool wave_risky,
+  template <class STACK>
+  __device__ __forceinline__ void node_step(const uint4* __restrict__ nodes, const STACK& stk, bool wave_risky,
                                             const lds_u4* top, uint32_t top_nodes) {
     const uint32_t hits = ng.y;
     const int b = 31 - __clz((int)hits);
     ng.y &= ~(1u << b);
     if (ng.y > 0x00FFFFFFu) { stk.put(sp, ng); ++sp; }
-    const uint32_t slot = ((uint32_t)b - 24u) ^ oct;
+    const uint32_t slot = ((uint32_t)b - 24u) ^ oct();
     const uint32_t rel = __popc(hits & ~(0xFFFFFFFFu << slot));
     // byte offset in 32 bits (pt_scene_create rejects BVHs beyond 4 GB of nodes): x80 as shift-adds, base stays scalar
     const uint32_t ni = ng.x + rel;

@@ -935,7 +935,7 @@ def test_shared_triangle_phase_gives_the_same_hit_records(ctx, oracle, pairs):
 
 
 def test_shared_triangle_phase_auto_choice_times_both_and_keeps_the_image(ctx, oracle):
-    """PT_OPT_SHARED_TRIANGLE_PHASE = 2 (default): the first large batch of a scene traces its bounce-1 queue twice more under
+    """PT_OPT_SHARED_TRIANGLE_PHASE = 2 (default): the first large batch of a scene traces one secondary-bounce queue twice more under
     events; a later call reads the timings and fixes the choice. The accumulated image is the same bits as with the option
     off, whatever it chose."""
     atm = oracle.earth_atmosphere()
