@@ -257,7 +257,7 @@ def measure_extend(pt, ctx, api, step, W, H, SPP, depth, sample0, steps, leg):
         "triangle_phase": {"option": leg.get("shared_triangle_phase", 2), "choice": int(se.shared_choice), "shared_used": shared_used,
                            "timed_ms_per_lane": round(se.shared_cal_ms[0], 4), "timed_ms_shared": round(se.shared_cal_ms[1], 4),
                            "note": "PT_OPT_SHARED_TRIANGLE_PHASE: the wave pools its rays' pending leaf records and tests them 64 at a time; "
-                                   "option 2 times both forms on a secondary-bounce queue of the warm-up step and keeps the shared one if it wins by 1 %"},
+                                   "option 2 times one batch of each form during the warm-up steps (the secondary bounces of two consecutive batches) and keeps the shared one if its batch was faster by 1 %"},
         "bytes_per_launch": round(alg_bytes, 1),
         "extend_share_of_render": round(se.extend_ms / max(se.render_ms, 1e-9), 4),
         "extend_mrays_per_s": round(se.rays / max(ext_s, 1e-12) / 1e6, 2),
@@ -283,16 +283,17 @@ def run_config_leg(pt, ctx, api, ptdist, dev, spec):
 
     def step(first):
         ctx.render(consts, W, H, first, SPP)
-    step(0)                      # warm-up (and the one-off primary-kernel timing of this scene / frame size)
+    for i in range(4):           # warm-up: the one-off primary-kernel timing of this scene / frame size, and the three batches the
+        step(i * SPP)            # library times its triangle phases on (PT_OPT_SHARED_TRIANGLE_PHASE = 2)
     ctx.synchronize()
     ctx.stats_reset()
     t0 = time.perf_counter()
     for i in range(steps):
-        step((1 + i) * SPP)
+        step((4 + i) * SPP)
     ctx.synchronize()
     t1 = time.perf_counter()
     st = ctx.stats()
-    roof = measure_extend(pt, ctx, api, step, W, H, SPP, depth, (2 + steps) * SPP, steps, spec)
+    roof = measure_extend(pt, ctx, api, step, W, H, SPP, depth, (5 + steps) * SPP, steps, spec)
     ctx.set_option(api.PT_OPT_RUSSIAN_ROULETTE, 0)
     ctx.synchronize()
     del target

@@ -105,6 +105,9 @@ struct pt_ctx {
   // events (same hit records every time), and the next call reads them. Until then: per-lane.
   int shared_tri = 2;
   int shared_choice = -1;             // -1 = not timed yet
+  int shared_force = -1;              // the batch being queued runs this form whatever the choice (the timing's two batches)
+  int shared_cal_stage = 0;           // batches of this scene seen by the timing: 0 none, 1 one (untimed: first launches, cold caches), 2 per-lane timed, 3 both timed
+  uint64_t shared_cal_paths = 0;      // paths of the timed batches (both must be the same size)
   bool shared_cal_pending = false;
   std::pair<hipEvent_t, hipEvent_t> shared_cal_ev[2] = {{nullptr, nullptr}, {nullptr, nullptr}};   // per-lane, shared
   float shared_cal_ms[2] = {0.0f, 0.0f};
@@ -340,22 +343,38 @@ int check_consts(pt_ctx* ctx, const PtRtConsts* c, bool need_sky) {
 }
 
 bool use_shared_tri(const pt_ctx* ctx) {
-  return ctx->shared_possible && ctx->cfg.defer_entries > 0 && (ctx->shared_tri == 1 || (ctx->shared_tri == 2 && ctx->shared_choice == 1));
+  if (!ctx->shared_possible || ctx->cfg.defer_entries == 0) return false;
+  if (ctx->shared_force >= 0) return ctx->shared_force == 1;
+  return ctx->shared_tri == 1 || (ctx->shared_tri == 2 && ctx->shared_choice == 1);
 }
 
-// Reads the two timings of calibrate_shared_tri once they are there (blocks only if that batch is still running). The shared
-// phase must win by 1 % (scenes it does not suit lose by 3-5 %): within the timing noise the per-lane kernel is kept, so the choice is reproducible from run to run.
+// PT_OPT_SHARED_TRIANGLE_PHASE = 2. The two forms are timed where they run: of a scene's first large batches the first is
+// left alone (first launches, cold caches), the second runs the per-lane phase and the third the shared one, each between
+// two events that span its secondary bounces (extend and shade of bounces >= 1: the same work either way except for the
+// phase), and the shared form is kept if its batch was faster by 1 % (scenes it does not suit are within +-1 % either way) for the scene. No launch is added and nothing waits; this reads
+// the two times once both batches are through (it blocks only if the second one is still running). An earlier version
+// re-traced one bounce's queue twice on the spot: with the caches warmed by the trace just before, it saw 1-2 % on the
+// courtyard where the render gains 4-20 % per bounce.
+void drop_shared_cal(pt_ctx* ctx) {   // forget a timing in progress (scene change, destroy): its events go back to the pool
+  for (auto& ev : ctx->shared_cal_ev) {
+    if (ev.first) ctx->event_pool.push_back(ev);
+    ev = {nullptr, nullptr};
+  }
+  ctx->shared_cal_pending = false;
+  ctx->shared_cal_stage = 0;
+  ctx->shared_force = -1;
+}
+
 int resolve_shared_cal(pt_ctx* ctx) {
   if (!ctx->shared_cal_pending) return PT_OK;
   ctx->shared_cal_pending = false;
-  PT_HIP(hipEventSynchronize(ctx->shared_cal_ev[0].second));
+  PT_HIP(hipEventSynchronize(ctx->shared_cal_ev[1].second));
   for (int i = 0; i < 2; ++i) {
     ctx->shared_cal_ms[i] = 0.0f;
     PT_HIP(hipEventElapsedTime(&ctx->shared_cal_ms[i], ctx->shared_cal_ev[i].first, ctx->shared_cal_ev[i].second));
     ctx->event_pool.push_back(ctx->shared_cal_ev[i]);
     ctx->shared_cal_ev[i] = {nullptr, nullptr};
   }
-  if (ctx->shared_cal_ms[0] < 0.2f) return PT_OK;   // a near-empty queue says nothing: time a later batch
   ctx->shared_choice = ctx->shared_cal_ms[1] <= 0.99f * ctx->shared_cal_ms[0] ? 1 : 0;
   return PT_OK;
 }
@@ -444,27 +463,6 @@ int calibrate_primary_kernel(pt_ctx* ctx, const PtRtConsts& consts, uint32_t wid
   return PT_OK;
 }
 
-// PT_OPT_SHARED_TRIANGLE_PHASE = 2: one secondary-bounce queue of a batch (incoherent rays, already traced once by the caller: caches
-// warm, hit records in place) is traced again by the shared-phase instantiation and then by the per-lane one, each under a
-// pair of events. Every run writes the same hit records, so the render goes on unchanged; nothing waits here.
-int calibrate_shared_tri(pt_ctx* ctx, WavefrontBuffers& wb, uint32_t bounce) {
-  const int in = (int)(bounce & 1u);
-  uint32_t* count = wb.counters + CTR_AT(CTR_QCOUNT0 + bounce);
-  uint32_t* cursor = wb.counters + CTR_AT(CTR_WORK0 + bounce);
-  for (int pass = 0; pass < 2; ++pass) {
-    const int which = pass == 0 ? 1 : 0;   // shared first, per-lane second
-    ctx->shared_cal_ev[which] = get_event_pair(ctx);
-    LaunchCfg cfg = ctx->cfg;
-    cfg.shared_tri = which == 1;
-    PT_HIP(hipMemsetAsync(cursor, 0, sizeof(uint32_t), ctx->stream));
-    PT_HIP(hipEventRecord(ctx->shared_cal_ev[which].first, ctx->stream));
-    launch_extend(ctx->ds, wb.ray_o[in], wb.ray_d[in], 1, wb.hits, count, cursor, wb.stats, false, false, cfg, ctx->stream, nullptr);
-    PT_HIP(hipEventRecord(ctx->shared_cal_ev[which].second, ctx->stream));
-  }
-  ctx->shared_cal_pending = true;
-  return PT_OK;
-}
-
 }  // namespace
 
 extern "C" {
@@ -511,7 +509,7 @@ int pt_destroy(pt_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   collect_events(ctx);
-  (void)resolve_shared_cal(ctx);   // hands its events back to the pool
+  drop_shared_cal(ctx);
   for (auto& p : ctx->event_pool) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
   free_list(ctx->scene_allocs);
   if (ctx->instance_ext) (void)hipFree(ctx->instance_ext);
@@ -755,7 +753,7 @@ int pt_scene_create(pt_ctx* ctx, const PtMeshDesc* meshes, uint32_t num_meshes, 
   ctx->has_scene = true;
   ctx->packet_blocks = 0;   // depends on the scene (stack depth, record format)
   ctx->packet_choice = -1;
-  if (ctx->shared_cal_pending) (void)resolve_shared_cal(ctx);   // hands the events back
+  drop_shared_cal(ctx);
   ctx->shared_choice = -1;
   ctx->shared_cal_ms[0] = ctx->shared_cal_ms[1] = 0.0f;
   return PT_OK;
@@ -1014,11 +1012,12 @@ int pt_render(pt_ctx* ctx, const PtRtConsts* consts, uint32_t width, uint32_t he
   if (use_skyview) launch_skyview_lut(*consts, ctx->lut, ctx->skyview, ctx->stream);   // 64 Ki texels, a few microseconds
   const bool fused = ctx->fused_primary;   // primaries computed inside k_extend / k_shade instead of a k_generate pass
   ctx->last_render_fused = fused;
+  ctx->shared_force = -1;
   if ((rc = resolve_shared_cal(ctx)) != PT_OK) return rc;
-  // time the two triangle-phase variants on this call's first batch? (large batches only: the timing has to see the kernels
-  // at throughput; never while the caller is collecting statistics or timings of its own)
-  bool calibrate_shared = ctx->shared_tri == 2 && ctx->shared_choice < 0 && ctx->shared_possible && ctx->cfg.defer_entries > 0 && bounces >= 2 &&
-                          !ctx->count_traversal && !ctx->time_kernels && wh * std::min<uint64_t>(spb, num_samples) >= (1ull << 21);
+  // may batches of this call take part in the timing of the two triangle phases (resolve_shared_cal)? Large single-lane
+  // batches only, and never while the caller is collecting statistics or timings of its own
+  const bool may_time_shared = ctx->shared_tri == 2 && ctx->shared_possible && ctx->cfg.defer_entries > 0 && bounces >= 2 && !two_lanes &&
+                               !ctx->count_traversal && !ctx->time_kernels;
   bool packet = fused && ctx->primary_packet == 1 && !ctx->count_traversal;
   if (fused && ctx->primary_packet == 2 && !ctx->count_traversal) {
     if (ctx->packet_choice < 0 || ctx->packet_choice_w != width || ctx->packet_choice_h != height) {
@@ -1048,18 +1047,34 @@ int pt_render(pt_ctx* ctx, const PtRtConsts* consts, uint32_t width, uint32_t he
       if (fused) launch_primary_setup(*consts, *wbs[l], width, height, first_lane[l], k_lane[l], streams[l]);
       else launch_generate(*consts, *wbs[l], width, height, first_lane[l], k_lane[l], streams[l]);
     }
+    // this batch's part in the timing of the triangle phases: -1 none, 0 = the per-lane batch, 1 = the shared batch
+    int timed = -1;
+    if (may_time_shared && ctx->shared_choice < 0 && !ctx->shared_cal_pending && wh * k >= (1ull << 21)) {
+      if (ctx->shared_cal_stage == 0) ctx->shared_cal_stage = 1;
+      else if (ctx->shared_cal_stage == 1) { timed = 0; ctx->shared_cal_paths = wh * k; }
+      else if (ctx->shared_cal_stage == 2 && ctx->shared_cal_paths == wh * k) timed = 1;
+      else ctx->shared_cal_stage = 1;   // another batch size: start over with the next batch
+    }
+    if (timed >= 0) {
+      ctx->shared_force = timed;
+      if (ctx->shared_cal_ev[timed].first) ctx->event_pool.push_back(ctx->shared_cal_ev[timed]);   // (a timing that started over)
+      ctx->shared_cal_ev[timed] = get_event_pair(ctx);
+    }
     for (uint32_t b = 0; b < bounces; ++b) {
       const int in = (int)(b & 1u);
+      if (timed >= 0 && b == 1) PT_HIP(hipEventRecord(ctx->shared_cal_ev[timed].first, ctx->stream));
       for (int l = 0; l < n_lanes; ++l) {
         WavefrontBuffers& wb = *wbs[l];
         extend_one(ctx, wb.ray_o[in], wb.ray_d[in], 1, wb.hits, wb.counters + CTR_AT(CTR_QCOUNT0 + b), wb.counters + CTR_AT(CTR_WORK0 + b), (int)b, false, l,
                    (fused && b == 0) ? wb.gen : nullptr, /*packet=*/packet && b == 0);
-        if (calibrate_shared && b == (bounces >= 3 ? 2u : 1u) && l == 0) {   // the second bounce when there is one: rays as incoherent as they get
-          calibrate_shared = false;
-          if ((rc = calibrate_shared_tri(ctx, wb, b)) != PT_OK) return rc;
-        }
         launch_shade(*consts, ctx->ds, wb, (int)b, width, height, first_lane[l], wh * k_lane[l], ctx->russian_roulette, ctx->cfg, streams[l], fused);
       }
+    }
+    if (timed >= 0) {
+      PT_HIP(hipEventRecord(ctx->shared_cal_ev[timed].second, ctx->stream));
+      ctx->shared_force = -1;
+      ctx->shared_cal_stage = 2 + timed;
+      if (timed == 1) ctx->shared_cal_pending = true;
     }
     for (int l = 0; l < n_lanes; ++l)
       if (consts->mySampleSky) launch_sky(*consts, ctx->lut, use_skyview ? ctx->skyview : nullptr, *wbs[l], wh * k_lane[l], ctx->cfg, streams[l]);
