@@ -7,7 +7,7 @@ mkdir -p $OUT
 leg() {  # name, env string, bench args...
   local name=$1 envs=$2; shift 2
   local tag=$(echo "$envs" | tr ' =' '__')
-  env $envs timeout -k 10 300 python3 bench.py --no-cpu-baseline --no-configs --steps 3 --warmup 1 "$@" > $OUT/${name}_${tag}.json 2> $OUT/${name}_${tag}.err || { echo "$name $envs FAILED"; tail -3 $OUT/${name}_${tag}.err; return 1; }
+  env $envs timeout -k 10 300 python3 bench.py --no-cpu-baseline --no-configs --steps ${STEPS:-3} --warmup ${WARMUP:-4} "$@" > $OUT/${name}_${tag}.json 2> $OUT/${name}_${tag}.err || { echo "$name $envs FAILED"; tail -3 $OUT/${name}_${tag}.err; return 1; }
   python3 - "$OUT/${name}_${tag}.json" "$name" "$envs" <<'PY'
 import json, sys
 d = json.loads([l for l in open(sys.argv[1]) if l.startswith("{")][0])
@@ -16,6 +16,10 @@ print(f"{sys.argv[2]:12s} {sys.argv[3]:40s} whole {d['value']:8.1f} Mrays/s  sec
 PY
 }
 for E in "$@"; do
+  if [ -n "${ONLY:-}" ]; then
+    case $ONLY in courtyard) leg courtyard "$E" --workload courtyard --width 3840 --height 2160 --spp-per-step 16 --russian-roulette 1 || exit 1;; street_hard) leg street_hard "$E" --workload street_hard || exit 1;; *) leg $ONLY "$E" --workload $ONLY || exit 1;; esac
+    continue
+  fi
   leg atrium "$E" || exit 1
   leg street "$E" --workload street || exit 1
   leg street_hard "$E" --workload street_hard || exit 1
