@@ -263,6 +263,9 @@ def measure_extend(pt, ctx, api, step, W, H, SPP, depth, sample0, steps, leg):
         "extend_mrays_per_s": round(se.rays / max(ext_s, 1e-12) / 1e6, 2),
         "extend_mrays_per_s_by_bounce": [round(se.rays_bounce[b] / max(se.extend_ms_bounce[b], 1e-9) / 1e3, 1)
                                          for b in range(16) if se.rays_bounce[b] > 0],
+        "extend_ms_share_by_bounce": [round(se.extend_ms_bounce[b] / max(se.extend_ms, 1e-9), 4)
+                                      for b in range(16) if se.rays_bounce[b] > 0],
+        "rays_share_by_bounce": [round(se.rays_bounce[b] / max(se.rays, 1), 5) for b in range(16) if se.rays_bounce[b] > 0],
         "secondary_mrays_per_s": round(sum(se.rays_bounce[1:]) / max(sum(se.extend_ms_bounce[1:]), 1e-9) / 1e3, 1),
     }
 

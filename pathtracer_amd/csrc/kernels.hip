@@ -202,6 +202,15 @@ static_assert(64u * PT_SHARED_TAKE <= PT_SHARED_LIST, "a pass of the shared tria
 #ifndef PT_EXTEND_COMPACT_ADDR
 #define PT_EXTEND_COMPACT_ADDR(PAIRS, SHARED) ((PAIRS) && (SHARED))   // which instantiations rebuild their stack / queue addresses at every access (extend_kernel.inc)
 #endif
+#ifndef PT_EXTEND_MIN_CLAIM
+#define PT_EXTEND_MIN_CLAIM 4u   // rays of a wave's first claim when the queue has fewer than that per wave
+#endif
+#ifndef PT_EXTEND_STATIC_SHARE
+#define PT_EXTEND_STATIC_SHARE 64u  // a queue with at most this many rays per wave of the grid is dealt out statically (extend_kernel.inc)
+#endif
+#ifndef PT_EXTEND_STATIC_FIRST
+#define PT_EXTEND_STATIC_FIRST 0 // 0: a wave's first claim is static only when the queue has fewer than 64 rays per wave; 1: always (extend_kernel.inc)
+#endif
 #ifndef PT_EXTEND_NODE_STEPS
 #define PT_EXTEND_NODE_STEPS 3   // box tests per scheduler iteration of the deferred schedule (1..4; C2 extend: 6.79, 6.95, 6.98, 6.83 Grays/s)
 #endif

@@ -393,13 +393,19 @@ void extend_one(pt_ctx* ctx, const float4* ro, const float4* rd, uint32_t stride
     launch_extend_packet(ctx->ds, ro, rd, hits, count, cursor, ctx->packet_blocks, st, primary_gen);
     ctx->packet_launches++;
   } else if (lane >= 2) {
-    // frame lane: a small queue (at most max_rays rays) on a grid cut to two 64-ray claims per wave, so that the extend
-    // launches of several frames in flight are resident side by side instead of one persistent grid filling every CU
+    // frame lane: a small queue (at most max_rays rays) on a grid cut to 64 rays per wave, so that the extend launches of
+    // several frames in flight are resident side by side instead of one persistent grid filling every CU; at that size the
+    // kernel deals the queue out to its waves statically (extend_kernel.inc: no cursor traffic)
     DeviceScene ds2 = ctx->ds;
     ds2.spill = ctx->fl[lane - 2].spill;
     LaunchCfg cfg2 = ctx->cfg;
     cfg2.shared_tri = use_shared_tri(ctx);
-    const uint64_t grid_div = 512u;   // rays per block: 256 / 512 / 1024 / 2048 measured, 512 best by 5-8 %
+#ifndef PT_FRAME_LANE_GRID_DIV
+#define PT_FRAME_LANE_GRID_DIV 256u
+#endif
+    // rays per block. With every claim an atomic on the cursor, 512 was best of 256 / 512 / 1024 / 2048 by 5-8 %; with the
+    // static deal (at most 64 rays per wave): 128 / 256 / 384 -> 0.44 / 0.36 / 0.48 ms per 640x360 one-sample call on the atrium
+    const uint64_t grid_div = PT_FRAME_LANE_GRID_DIV;
     if (max_rays) cfg2.extend_blocks = (int)std::min<uint64_t>((uint64_t)cfg2.extend_blocks, std::max<uint64_t>((uint64_t)cfg2.num_cus, (max_rays + grid_div - 1) / grid_div));
     launch_extend(ds2, ro, rd, stride, hits, count, cursor, ctx->fl[lane - 2].wb.stats, ctx->count_traversal, any_hit, cfg2, st, primary_gen);
   } else if (lane) {

@@ -870,6 +870,33 @@ def test_extend_schedule_options_never_change_hits(ctx, oracle, fetch_min, postp
     assert np.array_equal(occ.astype(bool), hit)
 
 
+def test_queue_length_never_changes_hits(ctx, oracle):
+    """The traversal kernel deals a short queue (fewer than 64 rays per resident wave) out to its waves statically and
+    claims a long one from the cursor in chunks (extend_kernel.inc): every prefix of one ray set, on both sides of that
+    switch and at the sizes where a wave's share changes, gets the bits of the long launch, which match the oracle."""
+    sc = scenes.atrium(1)
+    ctx.scene_create(sc)
+    info = ctx.scene_info()
+    rays = random_rays(77, 700000, list(info.bounds_min), list(info.bounds_max), tmin=0.001, tmax=10000.0)
+    full = ctx.trace_rays(rays)
+    ref = oracle.scene(sc).trace_rays(rays[:30000])
+    assert np.array_equal(full["prim"][:30000], ref["prim"])
+    hit = ref["prim"] != api.PT_MISS
+    for f in ("t", "u", "v"):
+        assert np.array_equal(full[f][:30000][hit].view(np.uint32), ref[f][hit].view(np.uint32)), f
+    sizes = (1, 3, 4, 5, 63, 64, 65, 6143, 6144, 6145, 24577, 200001, 393215, 393216, 393217, 450000)
+    try:
+        for blocks in (0, 1):            # 0: the resident grid (6 blocks per CU); 1: a sixth of it, so the switch sits at a sixth of the length
+            ctx.set_tuning(api.PT_TUNE_EXTEND_BLOCKS_PER_CU, blocks)
+            for n in sizes if blocks == 0 else (5, 1025, 65535, 65536, 65537, 200001):
+                got = ctx.trace_rays(rays[:n])
+                assert np.array_equal(got.view(np.uint32), full[:n].view(np.uint32)), (blocks, n)
+            occ = ctx.occluded(rays[:50001])
+            assert np.array_equal(occ.astype(bool), full["prim"][:50001] != api.PT_MISS)
+    finally:
+        ctx.set_tuning(api.PT_TUNE_EXTEND_BLOCKS_PER_CU, 0)
+
+
 def test_fast_build_flag_gives_the_same_hits_with_a_plainer_tree(ctx, oracle):
     """PT_SCENE_FAST_BUILD skips the spatial splits and the optimisation pass over the binary tree: no reference is duplicated,
     the build is quicker, the hit records are the same bits (they never depend on the acceleration structure)."""

@@ -30,10 +30,12 @@ pmc_one street_hard 1920 1080 64 8 "" --workload street_hard
 pmc_one courtyard 3840 2160 16 16 russian_roulette=1 --workload courtyard --width 3840 --height 2160 --spp-per-step 16 --russian-roulette 1
 if [ "${PMC_VARIANTS:-1}" = 1 ]; then   # the variants the bench also reports: C4 with the GGX extension, C5 without Russian roulette
   mv gpurun_out/pmc_${TAG}_street gpurun_out/pmc_${TAG}_street_plain; mv gpurun_out/pmc_${TAG}_courtyard gpurun_out/pmc_${TAG}_courtyard_rr
+  cp gpurun_out/pmc_${TAG}_street_summary.txt gpurun_out/pmc_${TAG}_street_plain_summary.txt; cp gpurun_out/pmc_${TAG}_courtyard_summary.txt gpurun_out/pmc_${TAG}_courtyard_rr_summary.txt   # the variants below reuse the names
   pmc_one street 1920 1080 64 8 material_ext=1 --workload street --material-ext 1
   mv gpurun_out/pmc_${TAG}_street_summary.txt gpurun_out/pmc_${TAG}_street_ggx_summary.txt
   pmc_one courtyard 3840 2160 16 16 "" --workload courtyard --width 3840 --height 2160 --spp-per-step 16
   mv gpurun_out/pmc_${TAG}_courtyard_summary.txt gpurun_out/pmc_${TAG}_courtyard_no_rr_summary.txt
+  mv gpurun_out/pmc_${TAG}_street_plain_summary.txt gpurun_out/pmc_${TAG}_street_summary.txt; mv gpurun_out/pmc_${TAG}_courtyard_rr_summary.txt gpurun_out/pmc_${TAG}_courtyard_summary.txt
 fi
 # per-kernel time of the other workloads (the headline's trace is above)
 for w in street street_hard courtyard; do
