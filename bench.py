@@ -36,6 +36,7 @@ NODE_BYTES, TRI_BYTES, RAY_IO_BYTES = 80, 48, 48   # B_ray = 80*N
 NODE_FLOP, TRI_FLOP = 176.0, 45.0                  # F_ray = 8*22*N_node + 45*N_tri
 FP32_PEAK_TFLOPS = 157.3                           # MI355X_MICROARCH.md: peak fp32 vector
 L1_PEAK_GBS = 39321.6                              # vector L1 return path: 64 B/clk/CU x 256 CUs x 2.4 GHz
+LEG_WARMUP = 5                                     # untimed steps of a "configs" leg (the library times its triangle phases on a scene's first five batches)
 PMC_ROUNDS = ("r03", "r02")                        # profiles/<round>/pmc_traffic.json, newest first
 DEF_DEFER, DEF_POSTPONE = 4, 40                    # the library defaults (csrc/kernels.h LaunchCfg)
 # k_extend's own VALU roof: most of its vector instructions (min/max, selects, shifts, byte permutes, v_fma_mix) issue at
@@ -257,7 +258,7 @@ def measure_extend(pt, ctx, api, step, W, H, SPP, depth, sample0, steps, leg):
         "triangle_phase": {"option": leg.get("shared_triangle_phase", 2), "choice": int(se.shared_choice), "shared_used": shared_used,
                            "timed_ms_per_lane": round(se.shared_cal_ms[0], 4), "timed_ms_shared": round(se.shared_cal_ms[1], 4),
                            "note": "PT_OPT_SHARED_TRIANGLE_PHASE: the wave pools its rays' pending leaf records and tests them 64 at a time; "
-                                   "option 2 times one batch of each form during the warm-up steps (the secondary bounces of two consecutive batches) and keeps the shared one if its batch was faster by 1 %"},
+                                   "option 2 times two batches of each form, alternating, during the warm-up steps (the secondary bounces of a scene's second to fifth batch; the times below are the sums) and keeps the shared one if it was faster by 1.5 %"},
         "bytes_per_launch": round(alg_bytes, 1),
         "extend_share_of_render": round(se.extend_ms / max(se.render_ms, 1e-9), 4),
         "extend_mrays_per_s": round(se.rays / max(ext_s, 1e-12) / 1e6, 2),
@@ -286,17 +287,17 @@ def run_config_leg(pt, ctx, api, ptdist, dev, spec):
 
     def step(first):
         ctx.render(consts, W, H, first, SPP)
-    for i in range(4):           # warm-up: the one-off primary-kernel timing of this scene / frame size, and the three batches the
-        step(i * SPP)            # library times its triangle phases on (PT_OPT_SHARED_TRIANGLE_PHASE = 2)
+    for i in range(LEG_WARMUP):  # warm-up: the one-off primary-kernel timing of this scene / frame size, and the five batches the
+        step(i * SPP)            # library needs to time its triangle phases (PT_OPT_SHARED_TRIANGLE_PHASE = 2)
     ctx.synchronize()
     ctx.stats_reset()
     t0 = time.perf_counter()
     for i in range(steps):
-        step((4 + i) * SPP)
+        step((LEG_WARMUP + i) * SPP)
     ctx.synchronize()
     t1 = time.perf_counter()
     st = ctx.stats()
-    roof = measure_extend(pt, ctx, api, step, W, H, SPP, depth, (5 + steps) * SPP, steps, spec)
+    roof = measure_extend(pt, ctx, api, step, W, H, SPP, depth, (LEG_WARMUP + 1 + steps) * SPP, steps, spec)
     ctx.set_option(api.PT_OPT_RUSSIAN_ROULETTE, 0)
     ctx.synchronize()
     del target
@@ -330,7 +331,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--spp-per-step", type=int, default=64,

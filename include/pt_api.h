@@ -186,7 +186,7 @@ typedef struct PtStats {
   uint64_t packet_launches;      /* of those, launches of k_extend_packet (the coherent-primaries kernel, PT_OPT_PRIMARY_PACKET) */
   float packet_cal_ms[2];        /* PT_OPT_PRIMARY_PACKET = 2: what the one-off timing measured on <= 2^24 primaries: k_extend, k_extend_packet */
   uint64_t shared_launches;      /* traversal-kernel launches that ran the shared triangle phase (PT_OPT_SHARED_TRIANGLE_PHASE) */
-  float shared_cal_ms[2];        /* PT_OPT_SHARED_TRIANGLE_PHASE = 2: ms of the secondary bounces of the two timed batches: per-lane, shared */
+  float shared_cal_ms[2];        /* PT_OPT_SHARED_TRIANGLE_PHASE = 2: ms of the secondary bounces of the timed batches, two of each form summed: per-lane, shared */
   int32_t shared_choice;         /* its outcome: -1 = not timed yet (per-lane until then), 0 = per-lane, 1 = shared */
   uint32_t reserved1;
 } PtStats;
@@ -236,9 +236,9 @@ enum {
                                       wave pools the pending records of its 64 rays and tests them 64 at a time, whoever owns them (a hit goes
                                       back to its ray through an LDS minimum on (t, triangle id), so the closest hit and its tie-break are the
                                       same), 2 (default) = the faster of the two for this scene: of a scene's first pt_render batches of >= 2^21 paths the
-                                      first is left alone, the second runs the per-lane form and the third the shared one, each between two HIP
-                                      events, and a later call reads the two times (no launch is added, nothing blocks; until then the per-lane
-                                      form runs). Pays where leaves are big and uneven (long thin triangles, spatial
+                                      first is left alone and the next four run the per-lane form, the shared one, and both again, each between
+                                      two HIP events; a later call reads the times and keeps the shared form if its two batches together were
+                                      faster by 1.5 % (no launch is added, nothing blocks; until then the per-lane form runs). Pays where leaves are big and uneven (long thin triangles, spatial
                                       splits: +8 % on the SAH-hostile street), costs ~1 % on regular scenes. Same hit records either way. */
 };
 

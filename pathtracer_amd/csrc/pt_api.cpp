@@ -106,11 +106,11 @@ struct pt_ctx {
   int shared_tri = 2;
   int shared_choice = -1;             // -1 = not timed yet
   int shared_force = -1;              // the batch being queued runs this form whatever the choice (the timing's two batches)
-  int shared_cal_stage = 0;           // batches of this scene seen by the timing: 0 none, 1 one (untimed: first launches, cold caches), 2 per-lane timed, 3 both timed
+  int shared_cal_stage = 0;           // large batches of this scene seen by the timing: 0 none, 1 one (untimed: first launches, cold caches), 2..5 = 1..4 timed ones
   uint64_t shared_cal_paths = 0;      // paths of the timed batches (both must be the same size)
   bool shared_cal_pending = false;
-  std::pair<hipEvent_t, hipEvent_t> shared_cal_ev[2] = {{nullptr, nullptr}, {nullptr, nullptr}};   // per-lane, shared
-  float shared_cal_ms[2] = {0.0f, 0.0f};
+  std::pair<hipEvent_t, hipEvent_t> shared_cal_ev[4] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};   // per-lane, shared, per-lane, shared
+  float shared_cal_ms[2] = {0.0f, 0.0f};   // per-lane, shared: two batches each
   bool shared_possible = true;        // record indices fit the phase's 26-bit list entries
   uint64_t shared_launches = 0;
   int noalloc_blocks = 0;             // grid of pt_trace_rays_device_noalloc's extend instantiation (extend_grid)
@@ -349,12 +349,14 @@ bool use_shared_tri(const pt_ctx* ctx) {
 }
 
 // PT_OPT_SHARED_TRIANGLE_PHASE = 2. The two forms are timed where they run: of a scene's first large batches the first is
-// left alone (first launches, cold caches), the second runs the per-lane phase and the third the shared one, each between
-// two events that span its secondary bounces (extend and shade of bounces >= 1: the same work either way except for the
-// phase), and the shared form is kept if its batch was faster by 1 % (scenes it does not suit are within +-1 % either way) for the scene. No launch is added and nothing waits; this reads
-// the two times once both batches are through (it blocks only if the second one is still running). An earlier version
-// re-traced one bounce's queue twice on the spot: with the caches warmed by the trace just before, it saw 1-2 % on the
-// courtyard where the render gains 4-20 % per bounce.
+// left alone (first launches, cold caches) and the next four run the per-lane phase, the shared one, and both again, each
+// between two events that span its secondary bounces (extend and shade of bounces >= 1: the same work either way except
+// for the phase); the shared form is kept for the scene if its two batches together were faster by 1.5 % (scenes it does
+// not suit are within +-1 % either way). No launch is added and nothing waits; this reads the times once the four batches
+// are through (it blocks only if the last one is still running). Two earlier versions: re-tracing one bounce's queue
+// twice on the spot saw 1-2 % on the courtyard where the render gains 4-20 % per bounce (caches warmed by the trace just
+// before); one batch of each form drifted by up to 2 % between a scene's second and third batch, enough to flip the
+// courtyard (3 % apart) in one run of five.
 void drop_shared_cal(pt_ctx* ctx) {   // forget a timing in progress (scene change, destroy): its events go back to the pool
   for (auto& ev : ctx->shared_cal_ev) {
     if (ev.first) ctx->event_pool.push_back(ev);
@@ -368,14 +370,16 @@ void drop_shared_cal(pt_ctx* ctx) {   // forget a timing in progress (scene chan
 int resolve_shared_cal(pt_ctx* ctx) {
   if (!ctx->shared_cal_pending) return PT_OK;
   ctx->shared_cal_pending = false;
-  PT_HIP(hipEventSynchronize(ctx->shared_cal_ev[1].second));
-  for (int i = 0; i < 2; ++i) {
-    ctx->shared_cal_ms[i] = 0.0f;
-    PT_HIP(hipEventElapsedTime(&ctx->shared_cal_ms[i], ctx->shared_cal_ev[i].first, ctx->shared_cal_ev[i].second));
+  PT_HIP(hipEventSynchronize(ctx->shared_cal_ev[3].second));
+  ctx->shared_cal_ms[0] = ctx->shared_cal_ms[1] = 0.0f;
+  for (int i = 0; i < 4; ++i) {
+    float ms = 0.0f;
+    PT_HIP(hipEventElapsedTime(&ms, ctx->shared_cal_ev[i].first, ctx->shared_cal_ev[i].second));
+    ctx->shared_cal_ms[i & 1] += ms;
     ctx->event_pool.push_back(ctx->shared_cal_ev[i]);
     ctx->shared_cal_ev[i] = {nullptr, nullptr};
   }
-  ctx->shared_choice = ctx->shared_cal_ms[1] <= 0.99f * ctx->shared_cal_ms[0] ? 1 : 0;
+  ctx->shared_choice = ctx->shared_cal_ms[1] <= 0.985f * ctx->shared_cal_ms[0] ? 1 : 0;
   return PT_OK;
 }
 
@@ -1053,16 +1057,16 @@ int pt_render(pt_ctx* ctx, const PtRtConsts* consts, uint32_t width, uint32_t he
       if (fused) launch_primary_setup(*consts, *wbs[l], width, height, first_lane[l], k_lane[l], streams[l]);
       else launch_generate(*consts, *wbs[l], width, height, first_lane[l], k_lane[l], streams[l]);
     }
-    // this batch's part in the timing of the triangle phases: -1 none, 0 = the per-lane batch, 1 = the shared batch
+    // this batch's part in the timing of the triangle phases: -1 none, 0..3 = the timed batches (even: per-lane, odd: shared)
     int timed = -1;
     if (may_time_shared && ctx->shared_choice < 0 && !ctx->shared_cal_pending && wh * k >= (1ull << 21)) {
       if (ctx->shared_cal_stage == 0) ctx->shared_cal_stage = 1;
       else if (ctx->shared_cal_stage == 1) { timed = 0; ctx->shared_cal_paths = wh * k; }
-      else if (ctx->shared_cal_stage == 2 && ctx->shared_cal_paths == wh * k) timed = 1;
+      else if (ctx->shared_cal_stage <= 4 && ctx->shared_cal_paths == wh * k) timed = ctx->shared_cal_stage - 1;
       else ctx->shared_cal_stage = 1;   // another batch size: start over with the next batch
     }
     if (timed >= 0) {
-      ctx->shared_force = timed;
+      ctx->shared_force = timed & 1;
       if (ctx->shared_cal_ev[timed].first) ctx->event_pool.push_back(ctx->shared_cal_ev[timed]);   // (a timing that started over)
       ctx->shared_cal_ev[timed] = get_event_pair(ctx);
     }
@@ -1080,7 +1084,7 @@ int pt_render(pt_ctx* ctx, const PtRtConsts* consts, uint32_t width, uint32_t he
       PT_HIP(hipEventRecord(ctx->shared_cal_ev[timed].second, ctx->stream));
       ctx->shared_force = -1;
       ctx->shared_cal_stage = 2 + timed;
-      if (timed == 1) ctx->shared_cal_pending = true;
+      if (timed == 3) ctx->shared_cal_pending = true;
     }
     for (int l = 0; l < n_lanes; ++l)
       if (consts->mySampleSky) launch_sky(*consts, ctx->lut, use_skyview ? ctx->skyview : nullptr, *wbs[l], wh * k_lane[l], ctx->cfg, streams[l]);

@@ -11,10 +11,10 @@ mkdir -p gpurun_out/${TAG}_trace profiles/$TAG
 # the headline alone (no "configs" legs: their k_extend launches on other scenes would enter the per-kernel averages)
 timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${TAG}_trace -- python3 bench.py --no-cpu-baseline --no-configs > gpurun_out/${TAG}_trace/bench.json 2> gpurun_out/${TAG}_trace/bench.err || { echo "trace failed"; tail -3 gpurun_out/${TAG}_trace/bench.err; exit 1; }
 echo "trace ok"
-# which triangle phase does the library pick per workload (PT_OPT_SHARED_TRIANGLE_PHASE = 2 times one batch of each form during the warm-up steps)?
+# which triangle phase does the library pick per workload (PT_OPT_SHARED_TRIANGLE_PHASE = 2 times two batches of each form during the warm-up steps)?
 # The PMC passes then name it explicitly, like the primary kernel, so no timing launch enters the per-launch averages.
 choice() {
-  timeout -k 10 300 python3 bench.py --no-cpu-baseline --no-configs --steps 1 --warmup 4 "$@" 2> /dev/null | python3 -c "import json,sys; print(max(0, json.loads(sys.stdin.read().strip().splitlines()[-1])['roofline']['triangle_phase']['choice']))"
+  timeout -k 10 300 python3 bench.py --no-cpu-baseline --no-configs --steps 1 --warmup 5 "$@" 2> /dev/null | python3 -c "import json,sys; print(max(0, json.loads(sys.stdin.read().strip().splitlines()[-1])['roofline']['triangle_phase']['choice']))"
 }
 pmc_one() {   # <name> <w> <h> <spp> <depth> <extra pmc_traffic key=value or ''> <bench args...>
   local name=$1 w=$2 h=$3 spp=$4 depth=$5 extra=$6; shift 6
