@@ -99,10 +99,19 @@ static int g_russian_roulette = 0;
 
 struct SampleStats { uint64_t rays = 0, hits = 0, sky = 0, nodes = 0, tris = 0; };
 
+// Test probe (orc_bounce_rays): what one path carries INTO iteration `bounce` of the RayGen loop (PathTracing.hlsl:63-71):
+// the TraceRay arguments and the payload-derived state so far. `reached` stays false for a path that ended earlier.
+struct PathProbe {
+  uint32_t bounce = 0;
+  bool reached = false;
+  float3 origin, dir, transmission, luminance;
+  float tmin = 0.0f, tmax = 0.0f;
+};
+
 // RayGen — PathTracing.hlsl:40-138, one sample of one pixel. Returns the (scrubbed) luminance and the texel to write.
 static inline float3 RayGenSample(const Scene& S, const PtRtConsts& c, const uint16_t* lut, uint32_t px, uint32_t py,
                                   uint32_t resX, uint32_t resY, uint32_t frameSeed, int jitter_mode, int brute,
-                                  SampleStats& st, int& outX, int& outY, bool count_traversal) {
+                                  SampleStats& st, int& outX, int& outY, bool count_traversal, PathProbe* probe = nullptr) {
   uint4 rngState = InitRNG(px, py, frameSeed);
   float2 pixel = {(float)px, (float)py};
   float jx = GetRand01(rngState);
@@ -128,6 +137,11 @@ static inline float3 RayGenSample(const Scene& S, const PtRtConsts& c, const uin
   TraceCounters tc;
   for (uint32_t bounceIdx = 0u; bounceIdx <= c.myMaxRecursionDepth; ++bounceIdx) {
     hitInfo.myHasHit = false;
+    if (probe && bounceIdx == probe->bounce) {
+      probe->reached = true;
+      probe->origin = origin; probe->dir = dir; probe->tmin = tmin; probe->tmax = tmax;
+      probe->transmission = transmission; probe->luminance = luminance;
+    }
     st.rays++;
     PtHit h = brute ? trace_brute(S, origin, tmin, dir, tmax) : trace_bvh(S, origin, tmin, dir, tmax, count_traversal ? &tc : nullptr);
     if (h.prim != PT_MISS) ClosestHit(S, c, h, origin, dir, hitInfo);
@@ -408,6 +422,35 @@ void orc_primary_hits(void* s, const PtRtConsts* c, uint32_t w, uint32_t h, uint
       if (rays_out) {
         PtRay r = {{o.x, o.y, o.z}, 0.0f, {d.x, d.y, d.z}, 10000.0f};
         rays_out[i] = r;
+      }
+    }
+}
+
+// Test probe: the ray every path of sample index `sample` carries into iteration `bounce` of the RayGen loop
+// (PathTracing.hlsl:63-71; bounce 0 = the primary ray, bounce b = origin myHitPos / direction sampled at hit b-1, :126-127),
+// i.e. the content of the product's bounce-b ray queue, one row per pixel in row order. alive[i] = 0 for a path that ended
+// before (sky miss, last bounce, roulette); state (optional, 8 floats per pixel) = transmission rgb, 0, luminance rgb, 0 at
+// that point. What it isolates is ClosestHit (:16-38) and the loaders behind it: myHitPos, the interpolated and flipped
+// normal (through the sampled direction), colour and emission (through the state).
+void orc_bounce_rays(void* s, const PtRtConsts* c, const uint16_t* lut, uint32_t w, uint32_t h, uint32_t sample,
+                     uint32_t bounce, int brute, PtRay* rays, uint8_t* alive, float* state /*optional*/) {
+  const Scene& S = *(const Scene*)s;
+#pragma omp parallel for schedule(dynamic, 2)
+  for (int y = 0; y < (int)h; ++y)
+    for (uint32_t x = 0; x < w; ++x) {
+      SampleStats st; int ox, oy;
+      PathProbe pr;
+      pr.bounce = bounce;
+      RayGenSample(S, *c, lut, x, (uint32_t)y, w, h, sample, 0, brute, st, ox, oy, false, &pr);
+      const size_t i = (size_t)y * w + x;
+      alive[i] = pr.reached ? 1 : 0;
+      PtRay r = {{0.0f, 0.0f, 0.0f}, 0.0f, {0.0f, 0.0f, 0.0f}, 0.0f};
+      if (pr.reached) r = PtRay{{pr.origin.x, pr.origin.y, pr.origin.z}, pr.tmin, {pr.dir.x, pr.dir.y, pr.dir.z}, pr.tmax};
+      rays[i] = r;
+      if (state) {
+        float* q = state + i * 8;
+        q[0] = pr.reached ? pr.transmission.x : 0.0f; q[1] = pr.reached ? pr.transmission.y : 0.0f; q[2] = pr.reached ? pr.transmission.z : 0.0f; q[3] = 0.0f;
+        q[4] = pr.reached ? pr.luminance.x : 0.0f; q[5] = pr.reached ? pr.luminance.y : 0.0f; q[6] = pr.reached ? pr.luminance.z : 0.0f; q[7] = 0.0f;
       }
     }
 }

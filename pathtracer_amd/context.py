@@ -208,6 +208,9 @@ class Context:
         return out
 
     def debug_read_queue(self, bounce):
+        """The last pt_render batch's ray queue of `bounce` as RAY_DTYPE rows (queue order depends on block scheduling).
+        The queues of even and odd bounces ping-pong between two buffers: after a render only the queue of its LAST bounce
+        (and the one before it) is whole, an earlier queue's head has been overwritten by bounce + 2."""
         n = C.c_uint64()
         self._ck(self.lib.pt_debug_read_queue(self.h, bounce, None, 0, C.byref(n)))
         out = np.empty(n.value, dtype=api.RAY_DTYPE)

@@ -48,6 +48,7 @@ def load():
     lib.orc_scene_triangle.argtypes = [P, C.c_uint32, P, P]
     lib.orc_trace_rays.argtypes = [P, P, C.c_uint64, P, C.c_int, P]
     lib.orc_primary_hits.argtypes = [P, C.POINTER(api.PtRtConsts), C.c_uint32, C.c_uint32, C.c_uint32, P, C.c_int, P]
+    lib.orc_bounce_rays.argtypes = [P, C.POINTER(api.PtRtConsts), P, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, P, P, P]
     lib.orc_render.argtypes = [P, C.POINTER(api.PtRtConsts), P, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, P,
                                C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_int, P, P]
     lib.orc_render_ao.argtypes = [P, C.POINTER(api.PtRtConsts), P, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, P, C.c_int, P]
@@ -109,6 +110,17 @@ class OracleScene:
         self.lib.orc_primary_hits(self.h, C.byref(consts), w, h, sample, api.ptr(out), int(brute),
                                   api.ptr(rays) if want_rays else None)
         return (out, rays) if want_rays else out
+
+    def bounce_rays(self, consts, w, h, sample, bounce, lut=None, brute=False):
+        """The ray every path of one sample index carries into RayGen-loop iteration `bounce` (= the product's bounce-b
+        queue): (rays[h,w] RAY_DTYPE, alive[h,w] bool, state[h,w,8] = transmission rgb, 0, luminance rgb, 0)."""
+        rays = np.zeros((h, w), dtype=api.RAY_DTYPE)
+        alive = np.zeros((h, w), dtype=np.uint8)
+        state = np.zeros((h, w, 8), dtype=np.float32)
+        lut_p = api.ptr(np.ascontiguousarray(lut)) if lut is not None else None
+        self.lib.orc_bounce_rays(self.h, C.byref(consts), lut_p, w, h, sample, bounce, int(brute), api.ptr(rays),
+                                 api.ptr(alive), api.ptr(state))
+        return rays, alive.astype(bool), state
 
     def render(self, consts, w, h, first_sample, num_samples, lut=None, accum=None, n_prev=0, accum_mode=0,
                jitter_mode=0, brute=False, count_traversal=False, per_sample=False):

@@ -1471,6 +1471,67 @@ def test_packet_kernel_for_primaries_is_bit_identical_to_the_per_lane_traversal(
         ctx.set_option(api.PT_OPT_PRIMARY_PACKET, 2)
 
 
+@pytest.mark.parametrize("scene_name", ["cornell", "atrium", "atrium_ext"])
+def test_bounce_queues_match_the_oracle_path_probe(ctx, oracle, scene_name):
+    """SURVEY 8 rows a7-a9 in isolation (payload, ClosestHit PathTracing.hlsl:16-38, the loaders Common.hlsl:75-127):
+    the ray queue k_shade writes for bounce b is, row for row, what the oracle's RayGen loop carries into iteration b
+    (orc_bounce_rays): origin = myHitPos = origin + dir * t, direction sampled about the interpolated, viewer-facing
+    normal, TMin 0.001 / TMax 10000 (:126-127). Bounce 1: origins BIT-identical (no transcendental between the primary ray
+    and myHitPos), directions within the shading tolerance (2e-4 absolute on unit vectors; the kernels use the hardware
+    transcendental unit). Later bounces inherit the direction tolerance through the hit point, so their rows are
+    matched one to one by nearest neighbour and >= 99.8 % must agree (the rest are paths that took another triangle after
+    a last-ulp difference, as in the image tests). Queue lengths are exact at every bounce."""
+    from scipy.spatial import cKDTree
+    if scene_name == "cornell":
+        ctx.scene_create(scenes.cornell_box())
+        w, h = 96, 96
+        c = cornell_consts(w, h)
+    else:
+        sc = scenes.atrium(1)
+        ctx.scene_create(scenes.with_material_ext(sc) if scene_name == "atrium_ext" else sc)
+        w, h = 160, 96
+        c = lookat_consts(w, h, scenes.ATRIUM_CAM, depth=3)
+    osc = oracle.scene(scenes.cornell_box() if scene_name == "cornell" else
+                       (scenes.with_material_ext(scenes.atrium(1)) if scene_name == "atrium_ext" else scenes.atrium(1)))
+    atm = oracle.earth_atmosphere()
+    ctx.sky_set(atm)
+    lut = oracle.transmittance_lut(atm)
+    sample = 7
+    for b in (1, 2, 3):
+        # the queues ping-pong between two buffers, so only the LAST bounce's queue is whole after a render: one render per
+        # bounce with the recursion depth cut to it (a path's first b bounces do not depend on the depth)
+        c.myMaxRecursionDepth = b
+        ctx.accum_reset(w, h)
+        ctx.stats_reset()
+        ctx.render(c, w, h, sample, 1)
+        st = ctx.stats()
+        q = ctx.debug_read_queue(b)
+        r, alive, _ = osc.bounce_rays(c, w, h, sample, b, lut=lut)
+        ref = r[alive]
+        assert len(ref) > 0.05 * w * h, (b, len(ref))
+        assert abs(len(q) - len(ref)) <= max(1, len(ref) // 2000) * (b > 1), (b, len(q), len(ref))
+        assert len(q) == st.rays_bounce[b]
+        assert (q["tmin"] == np.float32(0.001)).all() and (q["tmax"] == np.float32(10000.0)).all()
+        if b == 1:
+            assert len(q) == len(ref)
+            ko = np.lexsort(ref["origin"].view(np.uint32).T[::-1])
+            kq = np.lexsort(q["origin"].view(np.uint32).T[::-1])
+            assert np.array_equal(q["origin"][kq].view(np.uint32), ref["origin"][ko].view(np.uint32))
+            uniq = np.ones(len(ko), dtype=bool)          # two paths on one hit point (none expected) would make the pairing ambiguous
+            same = (ref["origin"][ko][1:] == ref["origin"][ko][:-1]).all(axis=1)
+            uniq[1:] &= ~same
+            uniq[:-1] &= ~same
+            d = np.abs(q["dir"][kq] - ref["dir"][ko])[uniq]
+            assert uniq.mean() > 0.99 and d.max() < 2e-4, (uniq.mean(), d.max())
+            continue
+        extent = float(np.ptp(ref["origin"], axis=0).max())
+        feat = lambda a: np.concatenate([a["origin"] / extent, a["dir"]], axis=1).astype(np.float64)
+        dist, idx = cKDTree(feat(q)).query(feat(ref), k=1)
+        ok = dist < 2e-3
+        assert ok.mean() >= 0.998, (b, ok.mean(), np.sort(dist)[-5:])
+        assert len(np.unique(idx[ok])) == int(ok.sum())   # one to one
+
+
 # ---------------------------------------------------------------------------------------------- API behaviour
 def test_default_batch_shrinks_when_device_memory_is_short():
     """The default wavefront batch is 2^27 paths (20 GB). When that much device memory is not free, pt_render halves the

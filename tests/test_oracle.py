@@ -149,6 +149,37 @@ def test_cornell_image_pinned(oracle):
     assert np.isfinite(acc).all() and acc[..., :3].max() > 1.0   # the light is visible
 
 
+def test_bounce_ray_probe_is_consistent_with_the_render(oracle):
+    """orc_bounce_rays (the probe the GPU queue test compares against) against the oracle's own other entry points:
+    bounce 0 is the primary ray of orc_primary_hits, the rays of all bounces add up to the render's ray count, a bounce-1
+    origin is primary origin + dir * t in fp32 (myHitPos, PathTracing.hlsl:23), the state at bounce 0 is T = 1, L = 0, and
+    the luminance carried into the bounce after the light was hit holds its emission."""
+    osc = oracle.scene(scenes.cornell_box())
+    w = h = 40
+    c = cornell_consts(w, h)
+    depth = int(c.myMaxRecursionDepth)
+    hits, prim = osc.primary_hits(c, w, h, 5, want_rays=True)
+    r0, a0, s0 = osc.bounce_rays(c, w, h, 5, 0)
+    assert a0.all() and np.array_equal(r0.view(np.uint32), prim.view(np.uint32))
+    assert (s0[..., :3] == 1).all() and (s0[..., 4:7] == 0).all()
+    total = 0
+    for b in range(depth + 2):
+        r, a, s = osc.bounce_rays(c, w, h, 5, b)
+        total += int(a.sum())
+        if b == 1:
+            hit = hits["prim"] != api.PT_MISS
+            assert np.array_equal(a, hit)
+            pos = (prim["origin"] + prim["dir"] * hits["t"][..., None]).astype(np.float32)
+            assert np.array_equal(r["origin"][a].view(np.uint32), pos[a].view(np.uint32))
+            assert (r["tmin"][a] == np.float32(0.001)).all() and (r["tmax"][a] == np.float32(10000.0)).all()
+            np.testing.assert_allclose(np.linalg.norm(r["dir"][a], axis=1), 1.0, atol=1e-5)
+            assert (s[..., 4:7][a].max(axis=1) > 0).any()       # some primaries hit the light: its emission is in L already
+        if b == depth + 1:
+            assert not a.any()                                   # the loop runs bounces 0 … depth
+    _, st, _ = osc.render(c, w, h, 5, 1)
+    assert total == st["rays"]
+
+
 def test_running_mean_equals_sum_over_n(oracle):
     """The reference's running mean (PathTracing.hlsl:134-137) vs the product's sum target: same image."""
     osc = oracle.scene(scenes.cornell_box())
