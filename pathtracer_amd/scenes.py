@@ -22,6 +22,9 @@ _ASSETS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "assets")
 
 # ----------------------------------------------------------------------------------------------- OBJ / MTL
 def _parse_mtl(path):
+    """Kd / Ke (the reference's two material inputs, PathTracer.cpp:142-160) and, for the material extension, the PBR
+    statements of MTL: `Pr` roughness and `Pm` metallic (either one selects the GGX model), `map_Kd [-s su sv sw] file`
+    (base-colour image; -s = uv scale) and the non-standard `pt_albedo_pattern <id> <scale>` for the procedural patterns."""
     mats, cur = {}, None
     if not os.path.exists(path):
         return mats
@@ -35,7 +38,36 @@ def _parse_mtl(path):
                 mats[cur] = {"Kd": (1.0, 1.0, 1.0), "Ke": (0.0, 0.0, 0.0)}
             elif cur and t[0] in ("Kd", "Ke") and len(t) >= 4:
                 mats[cur][t[0]] = tuple(float(x) for x in t[1:4])
+            elif cur and t[0] in ("Pr", "Pm") and len(t) >= 2:
+                mats[cur][t[0]] = float(t[1])
+            elif cur and t[0] == "pt_albedo_pattern" and len(t) >= 3:
+                mats[cur]["pattern"] = (int(t[1]), float(t[2]))
+            elif cur and t[0] == "map_Kd" and len(t) >= 2:
+                scale, k, name = 1.0, 1, None
+                while k < len(t):                       # options: "-s u v w", "-o …", "-clamp on", …; the file name comes last
+                    if t[k].startswith("-") and len(t[k]) > 1 and not t[k][1].isdigit() and k < len(t) - 1:
+                        opt, k = t[k], k + 1
+                        vals = []
+                        while k < len(t) - 1 and (t[k] in ("on", "off") or _is_number(t[k])):
+                            vals.append(t[k])
+                            k += 1
+                        if opt == "-s" and vals and _is_number(vals[0]):
+                            scale = float(vals[0])
+                    else:
+                        name = " ".join(t[k:])
+                        break
+                if name is None:
+                    raise ValueError(f"{path}:{lineno}: map_Kd without a file name")
+                mats[cur]["map_Kd"] = (os.path.join(os.path.dirname(path), name.replace("\\", "/")), scale)
     return mats
+
+
+def _is_number(tok):
+    try:
+        float(tok)
+        return True
+    except ValueError:
+        return False
 
 
 def load_obj(path):
@@ -122,15 +154,64 @@ def load_obj(path):
         meshes.append((v, np.array(idx, dtype=np.uint32)))
         instances.append((len(meshes) - 1, mat_names.index(m) if m in mat_names else 0, None))
     materials = [(mtl[n]["Ke"], tuple(mtl[n]["Kd"]) + (1.0,)) for n in mat_names]
-    return SceneData(meshes, instances, materials, name=os.path.basename(path))
+    scene = SceneData(meshes, instances, materials, name=os.path.basename(path))
+    _attach_material_ext(scene, [mtl[n] for n in mat_names])
+    return scene
+
+
+def _attach_material_ext(scene, mats):
+    """MTL PBR statements -> SceneData.materials_ext / albedo_texture (the material extension; include/pt_api.h
+    PtMaterialExt). The device holds ONE albedo image per scene (pt_scene_set_albedo_texture): the first map_Kd file in
+    material order is decoded (image_io.read_image_rgba8: 8-bit PNG, binary PPM) and every material naming it samples it;
+    materials naming another file keep their plain Kd and are listed in scene.skipped_textures (with a warning)."""
+    if not any(k in m for m in mats for k in ("Pr", "Pm", "map_Kd", "pattern")):
+        return
+    from . import image_io
+    tex_path, skipped, ext = None, [], []
+    for m in mats:
+        pattern, scale = m.get("pattern", (0, 1.0))
+        if "map_Kd" in m:
+            f, sc = m["map_Kd"]
+            if tex_path is None:
+                tex_path = f
+            if os.path.normpath(f) == os.path.normpath(tex_path):
+                pattern, scale = 3, sc
+            else:
+                skipped.append(f)
+        ggx = "Pr" in m or "Pm" in m
+        ext.append((float(m.get("Pr", 0.5)), float(m.get("Pm", 0.0)), int(pattern), float(scale), api.PT_MAT_GGX if ggx else 0))
+    scene.materials_ext = ext
+    scene.skipped_textures = skipped
+    if tex_path is not None:
+        scene.albedo_texture = image_io.read_image_rgba8(tex_path)
+    if skipped:
+        import warnings
+        warnings.warn(f"{scene.name}: one albedo image per scene; {len(set(skipped))} further map_Kd file(s) ignored "
+                      f"(those materials keep their Kd): {sorted(set(skipped))[:3]}")
 
 
 def scene_to_obj(scene, path):
-    """Write a SceneData as OBJ + MTL (one group per instance, %.9g so fp32 values round-trip exactly)."""
+    """Write a SceneData as OBJ + MTL (one group per instance, %.9g so fp32 values round-trip exactly). A material
+    extension goes out as Pr / Pm (GGX materials), pt_albedo_pattern (procedural patterns) and map_Kd -s (the albedo
+    image, written beside the MTL as <name>_albedo.png), which load_obj reads back."""
     mtl_path = os.path.splitext(path)[0] + ".mtl"
+    ext = getattr(scene, "materials_ext", None)
+    tex_name = None
+    if ext and getattr(scene, "albedo_texture", None) is not None and any(e[2] == 3 for e in ext):
+        from . import image_io
+        tex_name = os.path.basename(os.path.splitext(path)[0]) + "_albedo.png"
+        image_io.write_png_rgba8(os.path.join(os.path.dirname(path), tex_name), scene.albedo_texture)
     with open(mtl_path, "w") as f:
         for k, (e, c) in enumerate(scene.materials):
             f.write(f"newmtl m{k}\nKd {c[0]:.9g} {c[1]:.9g} {c[2]:.9g}\nKe {e[0]:.9g} {e[1]:.9g} {e[2]:.9g}\n")
+            if ext:
+                rough, metal, pattern, scale, flags = ext[k]
+                if flags & api.PT_MAT_GGX:
+                    f.write(f"Pr {rough:.9g}\nPm {metal:.9g}\n")
+                if pattern == 3 and tex_name:
+                    f.write(f"map_Kd -s {scale:.9g} {scale:.9g} 1 {tex_name}\n")
+                elif pattern:
+                    f.write(f"pt_albedo_pattern {int(pattern)} {scale:.9g}\n")
     with open(path, "w") as f:
         f.write(f"mtllib {os.path.basename(mtl_path)}\n")
         off = 0
@@ -142,9 +223,11 @@ def scene_to_obj(scene, path):
                 f.write(f"v {p[0]:.9g} {p[1]:.9g} {p[2]:.9g}\n")
             for n in v["normal"]:
                 f.write(f"vn {n[0]:.9g} {n[1]:.9g} {n[2]:.9g}\n")
+            for u in v["uv"]:
+                f.write(f"vt {u[0]:.9g} {u[1]:.9g}\n")
             f.write(f"usemtl m{mat}\n")
             for a, b, c in idx.reshape(-1, 3) + 1 + off:
-                f.write(f"f {a}//{a} {b}//{b} {c}//{c}\n")
+                f.write(f"f {a}/{a}/{a} {b}/{b}/{b} {c}/{c}/{c}\n")
             off += len(v)
 
 

@@ -1725,3 +1725,36 @@ def test_cpp_host_cli_matches_python_host(ctx, tmp_path):
     assert np.array_equal(img, ref[..., :3])
     bad = subprocess.run([cli, str(tmp_path / "missing.obj"), out], capture_output=True, text=True, timeout=60)
     assert bad.returncode == 1 and "Failed importing scene" in bad.stderr
+
+
+def test_textured_obj_file_renders_like_the_scene_it_was_written_from(ctx, oracle, tmp_path):
+    """Scene ingestion of the material extension from files (MTL Pr / Pm / map_Kd -s / pt_albedo_pattern + an 8-bit PNG):
+    a scene with every albedo kind and both material models, written by scene_to_obj and read back by load_obj (the path
+    PathTracer.LoadScene takes for a file name), renders to the SAME bits as the in-memory scene, and within the image
+    tolerance of the oracle given the file-loaded scene."""
+    soup = scenes.random_triangle_soup(3, 3000, extent=6.0, size=1.5)
+    v, i = soup.meshes[0]
+    v["uv"] = np.random.default_rng(4).random((len(v), 2)).astype(np.float32) * 3.0
+    parts = np.array_split(i.reshape(-1, 3), 6)
+    sc = SceneData([(v, p.reshape(-1)) for p in parts], [(k, k, None) for k in range(6)],
+                   [((0.3, 0.3, 0.3) if k == 5 else (0.0, 0.0, 0.0), (0.2 + 0.1 * k, 0.6, 0.9 - 0.1 * k, 1.0)) for k in range(6)])
+    sc = scenes.with_material_ext(sc, seed=9)
+    obj = str(tmp_path / "tex.obj")
+    scenes.scene_to_obj(sc, obj)
+    assert os.path.exists(str(tmp_path / "tex_albedo.png"))
+    back = scenes.load_obj(obj)
+    assert back.albedo_texture is not None and [e[2] for e in back.materials_ext] == [0, 1, 2, 3, 0, 1]
+    w, h, spp = 160, 96, 8
+    c = lookat_consts(w, h, {"eye": (3.0, 3.0, -7.0), "target": (3.0, 3.0, 3.0)}, depth=3)
+    c.myLightInstanceId = 0xFFFFFFFF
+    ctx.sky_set(oracle.earth_atmosphere())
+    imgs = []
+    for s in (sc, back):
+        ctx.scene_create(s)
+        ctx.accum_reset(w, h)
+        ctx.render(c, w, h, 0, spp)
+        imgs.append(ctx.accum_read_sum()[0].copy())
+    assert np.array_equal(imgs[0].view(np.uint32), imgs[1].view(np.uint32))
+    lut = oracle.transmittance_lut(oracle.earth_atmosphere())
+    ref, _, _ = oracle.scene(back).render(c, w, h, 0, spp, lut=lut)
+    assert rel_mse(imgs[1][..., :3] / spp, ref[..., :3] / spp) < 1e-4

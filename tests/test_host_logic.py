@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 from pathtracer_amd import api, scenes
-from pathtracer_amd.context import SceneData, encode_unorm_rgba, pack_scene
+from pathtracer_amd.context import SceneData, encode_unorm_rgba, pack_material_ext, pack_scene
 from pathtracer_amd.distributed import partition_samples
 from pathtracer_amd.pathtracer import Camera, SetupEarthAtmosphere
 from tests.common import cornell_camera, cornell_consts
@@ -124,6 +124,123 @@ def test_obj_reader_roundtrip(tmp_path):
     np.testing.assert_allclose(v2["normal"], [[0, 0, 1]] * 3)    # no vn: face normal
     m, nm, ins, ni, mats, nmat, keep = pack_scene(sc)
     assert (nm, ni, nmat) == (2, 2, 2) and m[0].num_triangles == 2 and list(ins[1].myTransform)[::5] == [1.0] * 4
+
+
+def _png_bytes(w, h, ctype, px, filters, plte=None, trns=None):
+    """A PNG encoder for the reader test only: 8-bit samples `px` (h, w, channels) with the given row filter per row."""
+    import struct
+    import zlib
+    ch = px.shape[2]
+    rows, prev = [], np.zeros(w * ch, dtype=np.int32)
+    for y in range(h):
+        cur = px[y].reshape(-1).astype(np.int32)
+        left = np.concatenate([np.zeros(ch, dtype=np.int32), cur[:-ch]])
+        upleft = np.concatenate([np.zeros(ch, dtype=np.int32), prev[:-ch]])
+        ft = filters[y % len(filters)]
+        if ft == 0:
+            pred = 0
+        elif ft == 1:
+            pred = left
+        elif ft == 2:
+            pred = prev
+        elif ft == 3:
+            pred = (left + prev) >> 1
+        else:
+            pa, pb, pc = np.abs(prev - upleft), np.abs(left - upleft), np.abs(left + prev - 2 * upleft)
+            pred = np.where((pa <= pb) & (pa <= pc), left, np.where(pb <= pc, prev, upleft))
+        rows.append(bytes([ft]) + ((cur - pred) & 255).astype(np.uint8).tobytes())
+        prev = cur
+    chunk = lambda tag, d: struct.pack(">I", len(d)) + tag + d + struct.pack(">I", zlib.crc32(tag + d) & 0xFFFFFFFF)
+    raw = zlib.compress(b"".join(rows))
+    out = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, ctype, 0, 0, 0))
+    if plte is not None:
+        out += chunk(b"PLTE", plte.tobytes())
+    if trns is not None:
+        out += chunk(b"tRNS", trns.tobytes())
+    return out + chunk(b"IDAT", raw[:len(raw) // 2]) + chunk(b"IDAT", raw[len(raw) // 2:]) + chunk(b"IEND", b"")
+
+
+def test_png_and_ppm_readers(tmp_path):
+    """Texture files for the albedo image (BASELINE C4 'textured'): 8-bit PNG in every colour type, with all
+    five row filters and split IDAT chunks, and binary PPM, decode to the RGBA8 texels pt_scene_set_albedo_texture takes;
+    damaged or unsupported files are a ValueError."""
+    from pathtracer_amd import image_io as io
+    rng = np.random.default_rng(5)
+    w, h = 11, 9
+    for ctype, ch in ((0, 1), (2, 3), (4, 2), (6, 4)):
+        px = rng.integers(0, 256, (h, w, ch), dtype=np.uint8)
+        f = tmp_path / f"t{ctype}.png"
+        f.write_bytes(_png_bytes(w, h, ctype, px, [4, 1, 3, 2, 0]))
+        img = io.read_image_rgba8(str(f))
+        want = np.full((h, w, 4), 255, dtype=np.uint8)
+        if ctype == 0:
+            want[..., :3] = px
+        elif ctype == 4:
+            want[..., :3], want[..., 3] = px[..., :1], px[..., 1]
+        else:
+            want[..., :ch] = px
+        assert np.array_equal(img, want), ctype
+    plte = rng.integers(0, 256, (5, 3), dtype=np.uint8)
+    trns = np.array([0, 128, 200], dtype=np.uint8)
+    idx = rng.integers(0, 5, (h, w, 1), dtype=np.uint8)
+    (tmp_path / "p.png").write_bytes(_png_bytes(w, h, 3, idx, [0, 2], plte, trns))
+    img = io.read_png(str(tmp_path / "p.png"))
+    assert np.array_equal(img[..., :3], plte[idx[..., 0]])
+    assert np.array_equal(img[..., 3], np.array([0, 128, 200, 255, 255], dtype=np.uint8)[idx[..., 0]])
+    a = rng.integers(0, 256, (h, w, 4), dtype=np.uint8)
+    io.write_png_rgba8(str(tmp_path / "w.png"), a)
+    assert np.array_equal(io.read_png(str(tmp_path / "w.png")), a)
+    (tmp_path / "c.ppm").write_bytes(b"P6\n# a comment\n%d %d\n255\n" % (w, h) + a[..., :3].tobytes())
+    assert np.array_equal(io.read_image_rgba8(str(tmp_path / "c.ppm"))[..., :3], a[..., :3])
+    good = (tmp_path / "w.png").read_bytes()
+    for name, data in (("crc", good[:40] + bytes([good[40] ^ 1]) + good[41:]), ("sig", b"GIF89a" + good[6:]), ("cut", good[:30]),
+                       ("deep", _png_bytes(w, h, 2, a[..., :3], [0]).replace(b"\x08\x02\x00\x00\x00", b"\x10\x02\x00\x00\x00", 1))):
+        (tmp_path / f"{name}.png").write_bytes(data)
+        with pytest.raises(ValueError):
+            io.read_image_rgba8(str(tmp_path / f"{name}.png"))
+
+
+def test_textured_obj_mtl_roundtrip(tmp_path):
+    """MTL PBR statements (Pr / Pm, map_Kd with -s, pt_albedo_pattern) become the material extension and its albedo image:
+    scene_to_obj -> load_obj gives back the uv, the extension tuples and the texels; a hand-written MTL with options
+    before the file name, a second texture file (ignored with a warning: one image per scene) and a PPM texture."""
+    from pathtracer_amd import image_io as io
+    soup = scenes.random_triangle_soup(3, 40)
+    v, i = soup.meshes[0]
+    v["uv"] = np.random.default_rng(4).random((len(v), 2)).astype(np.float32)
+    sc = SceneData([(v, i)], [(0, k, None) for k in range(6)],                 # six materials: every albedo kind, both models
+                   [((0.0, 0.0, 0.0), (0.1 + 0.1 * k, 0.5, 0.9 - 0.1 * k, 1.0)) for k in range(6)])
+    sc = scenes.with_material_ext(sc, seed=9)
+    obj = str(tmp_path / "s.obj")
+    scenes.scene_to_obj(sc, obj)
+    back = scenes.load_obj(obj)
+    assert back.num_triangles == sc.num_triangles and len(back.materials) == len(sc.materials)
+    pa, pb = (np.concatenate([x.meshes[m][0]["pos"][x.meshes[m][1]] for m, _, _ in x.instances]) for x in (sc, back))
+    ua, ub = (np.concatenate([x.meshes[m][0]["uv"][x.meshes[m][1]] for m, _, _ in x.instances]) for x in (sc, back))
+    assert np.array_equal(pa, pb) and np.array_equal(ua, ub)            # corner by corner: positions and uv round-trip exactly
+    assert np.array_equal(back.albedo_texture, sc.albedo_texture)
+    for (r0, m0, p0, s0, f0), (r1, m1, p1, s1, f1) in zip(sc.materials_ext, back.materials_ext):
+        assert (p0, f0) == (p1, f1) and (p0 == 0 or np.float32(s0) == np.float32(s1))
+        if f0 & api.PT_MAT_GGX:
+            assert np.float32(r0) == np.float32(r1) and np.float32(m0) == np.float32(m1)
+    arr = pack_material_ext(back)
+    assert len(arr) == len(back.materials) and any(a.albedo_pattern == 3 for a in arr)
+
+    tex = np.random.default_rng(2).integers(0, 256, (4, 6, 3), dtype=np.uint8)
+    (tmp_path / "wall.ppm").write_bytes(b"P6 6 4 255\n" + tex.tobytes())
+    io.write_png_rgba8(str(tmp_path / "other.png"), np.zeros((2, 2, 4), dtype=np.uint8))
+    (tmp_path / "h.mtl").write_text("newmtl a\nKd 0.5 0.5 0.5\nmap_Kd -clamp off -s 4 4 1 -o 0 0 0 wall.ppm\nPr 0.25\n"
+                                    "newmtl b\nKd 1 0 0\nmap_Kd other.png\nnewmtl c\nKd 0 1 0\nPm 1\n")
+    (tmp_path / "h.obj").write_text("mtllib h.mtl\nv 0 0 0\nv 1 0 0\nv 0 1 0\nvt 0 0\nvt 1 0\nvt 0 1\nusemtl a\nf 1/1 2/2 3/3\n"
+                                    "usemtl b\nf 1/1 2/2 3/3\nusemtl c\nf 1/1 2/2 3/3\n")
+    with pytest.warns(UserWarning, match="one albedo image per scene"):
+        hs = scenes.load_obj(str(tmp_path / "h.obj"))
+    assert hs.materials_ext == [(0.25, 0.0, 3, 4.0, api.PT_MAT_GGX), (0.5, 0.0, 0, 1.0, 0), (0.5, 1.0, 0, 1.0, api.PT_MAT_GGX)]
+    assert hs.albedo_texture.shape == (4, 6, 4) and np.array_equal(hs.albedo_texture[..., :3], tex)
+    assert len(hs.skipped_textures) == 1 and hs.skipped_textures[0].endswith("other.png")
+    (tmp_path / "n.mtl").write_text("newmtl a\nKd 1 1 1\n")
+    (tmp_path / "n.obj").write_text("mtllib n.mtl\nv 0 0 0\nv 1 0 0\nv 0 1 0\nusemtl a\nf 1 2 3\n")
+    assert scenes.load_obj(str(tmp_path / "n.obj")).materials_ext is None     # no PBR statement: the reference's material model
 
 
 @pytest.mark.parametrize("face,what", [("f 1 2 9", "out of range"), ("f 0 1 2", "index"), ("f 1 2 -7", "out of range"),
