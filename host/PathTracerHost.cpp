@@ -1,6 +1,7 @@
 // PathTracerHost.cpp — see PathTracerHost.h. Reference: PathTracer/PathTracer.cpp, PathTracer/Sky.cpp.
 #include "PathTracerHost.h"
 
+#include <cctype>
 #include <cerrno>
 #include <climits>
 #include <cstdlib>
@@ -13,6 +14,8 @@
 #include <map>
 #include <sstream>
 #include <tuple>
+
+#include <zlib.h>
 
 namespace pth {
 
@@ -32,10 +35,17 @@ uint32_t Encode_Unorm_RGBA(const float c[4]) {
 }
 
 // ------------------------------------------------------------------------------------------------ OBJ / MTL
+static bool IsNumber(const std::string& t) {
+  char* end = nullptr;
+  std::strtod(t.c_str(), &end);
+  return !t.empty() && end && *end == '\0';
+}
+
 static std::map<std::string, MaterialDesc> ParseMtl(const std::string& aPath, std::vector<std::string>& anOrderOut) {
   std::map<std::string, MaterialDesc> mats;
   std::ifstream f(aPath);
   std::string line, cur;
+  const std::string dir = aPath.find_last_of("/\\") == std::string::npos ? "" : aPath.substr(0, aPath.find_last_of("/\\") + 1);
   while (std::getline(f, line)) {
     std::istringstream ss(line);
     std::string t;
@@ -43,8 +53,132 @@ static std::map<std::string, MaterialDesc> ParseMtl(const std::string& aPath, st
     if (t == "newmtl") { ss >> cur; mats[cur] = MaterialDesc(); anOrderOut.push_back(cur); }
     else if (!cur.empty() && t == "Kd") { ss >> mats[cur].myColor[0] >> mats[cur].myColor[1] >> mats[cur].myColor[2]; }
     else if (!cur.empty() && t == "Ke") { ss >> mats[cur].myEmission[0] >> mats[cur].myEmission[1] >> mats[cur].myEmission[2]; }
+    else if (!cur.empty() && t == "Pr") { ss >> mats[cur].myRoughness; mats[cur].myHasPbr = true; }
+    else if (!cur.empty() && t == "Pm") { ss >> mats[cur].myMetallic; mats[cur].myHasPbr = true; }
+    else if (!cur.empty() && t == "pt_albedo_pattern") { ss >> mats[cur].myAlbedoPattern >> mats[cur].myPatternScale; }
+    else if (!cur.empty() && t == "map_Kd") {
+      // options ("-s u v w", "-o …", "-clamp on", …) come first, the file name last
+      std::vector<std::string> tok;
+      std::string x;
+      while (ss >> x) tok.push_back(x);
+      size_t k = 0;
+      while (k < tok.size()) {
+        if (tok[k].size() > 1 && tok[k][0] == '-' && !std::isdigit((unsigned char)tok[k][1]) && k + 1 < tok.size()) {
+          const std::string opt = tok[k++];
+          std::vector<std::string> vals;
+          while (k + 1 < tok.size() && (tok[k] == "on" || tok[k] == "off" || IsNumber(tok[k]))) vals.push_back(tok[k++]);
+          if (opt == "-s" && !vals.empty() && IsNumber(vals[0])) mats[cur].myAlbedoMapScale = (float)std::atof(vals[0].c_str());
+        } else {
+          std::string name = tok[k];
+          for (size_t j = k + 1; j < tok.size(); ++j) name += " " + tok[j];
+          std::replace(name.begin(), name.end(), '\\', '/');
+          mats[cur].myAlbedoMap = dir + name;
+          break;
+        }
+      }
+    }
   }
   return mats;
+}
+
+// ------------------------------------------------------------------------------------------------ texture files
+static uint32_t Be32(const uint8_t* p) { return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3]; }
+
+static bool ReadPng(const std::vector<uint8_t>& d, const std::string& aPath, std::vector<uint8_t>& out, uint32_t& w, uint32_t& h, std::string* err) {
+  auto bad = [&](const std::string& what) { if (err) *err = aPath + ": " + what; return false; };
+  size_t pos = 8;
+  bool haveHdr = false;
+  uint32_t depth = 0, ctype = 0, interlace = 0;
+  std::vector<uint8_t> idat, plte, trns;
+  while (pos + 12 <= d.size()) {
+    const uint32_t n = Be32(&d[pos]);
+    if ((uint64_t)pos + 12 + n > d.size()) return bad("truncated chunk");
+    const uint8_t* tag = &d[pos + 4];
+    const uint8_t* body = &d[pos + 8];
+    if (Be32(&d[pos + 8 + n]) != (uint32_t)crc32(crc32(0L, Z_NULL, 0), tag, n + 4)) return bad("CRC mismatch");
+    const std::string t((const char*)tag, 4);
+    if (t == "IHDR" && n == 13) { w = Be32(body); h = Be32(body + 4); depth = body[8]; ctype = body[9]; interlace = body[12]; haveHdr = true; }
+    else if (t == "PLTE") plte.assign(body, body + n);
+    else if (t == "tRNS") trns.assign(body, body + n);
+    else if (t == "IDAT") idat.insert(idat.end(), body, body + n);
+    else if (t == "IEND") break;
+    pos += 12 + (size_t)n;
+  }
+  const uint32_t ch = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 3 ? 1 : ctype == 4 ? 2 : ctype == 6 ? 4 : 0;
+  if (!haveHdr || idat.empty()) return bad("no IHDR / IDAT");
+  if (depth != 8 || ch == 0 || interlace != 0 || w == 0 || h == 0 || (uint64_t)w * h > (1u << 28)) return bad("only 8-bit non-interlaced PNG is read");
+  const size_t stride = (size_t)w * ch;
+  std::vector<uint8_t> raw((stride + 1) * h);
+  uLongf rawLen = (uLongf)raw.size();
+  if (uncompress(raw.data(), &rawLen, idat.data(), (uLong)idat.size()) != Z_OK || rawLen != raw.size()) return bad("bad image data");
+  std::vector<uint8_t> px(stride * h), zero(stride, 0);
+  for (uint32_t y = 0; y < h; ++y) {
+    const uint8_t ft = raw[(stride + 1) * y];
+    const uint8_t* line = &raw[(stride + 1) * y + 1];
+    const uint8_t* up = y ? &px[stride * (y - 1)] : zero.data();
+    uint8_t* cur = &px[stride * y];
+    if (ft > 4) return bad("bad row filter");
+    for (size_t i = 0; i < stride; ++i) {
+      const int a = i >= ch ? cur[i - ch] : 0, b = up[i], c = i >= ch ? up[i - ch] : 0;
+      int pred = 0;
+      if (ft == 1) pred = a;
+      else if (ft == 2) pred = b;
+      else if (ft == 3) pred = (a + b) >> 1;
+      else if (ft == 4) { const int p = a + b - c, pa = std::abs(p - a), pb = std::abs(p - b), pc = std::abs(p - c); pred = (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c); }
+      cur[i] = (uint8_t)(line[i] + pred);
+    }
+  }
+  out.assign((size_t)w * h * 4, 255);
+  for (size_t i = 0; i < (size_t)w * h; ++i) {
+    const uint8_t* s = &px[i * ch];
+    uint8_t* o = &out[i * 4];
+    if (ctype == 0) { o[0] = o[1] = o[2] = s[0]; }
+    else if (ctype == 4) { o[0] = o[1] = o[2] = s[0]; o[3] = s[1]; }
+    else if (ctype == 2) { o[0] = s[0]; o[1] = s[1]; o[2] = s[2]; }
+    else if (ctype == 6) { o[0] = s[0]; o[1] = s[1]; o[2] = s[2]; o[3] = s[3]; }
+    else {
+      if ((size_t)s[0] * 3 + 2 >= plte.size()) return bad("palette index out of range");
+      o[0] = plte[s[0] * 3]; o[1] = plte[s[0] * 3 + 1]; o[2] = plte[s[0] * 3 + 2];
+      if (s[0] < trns.size()) o[3] = trns[s[0]];
+    }
+  }
+  return true;
+}
+
+static bool ReadPnm(const std::vector<uint8_t>& d, const std::string& aPath, std::vector<uint8_t>& out, uint32_t& w, uint32_t& h, std::string* err) {
+  auto bad = [&](const std::string& what) { if (err) *err = aPath + ": " + what; return false; };
+  std::vector<std::string> tok;
+  size_t pos = 0;
+  while (tok.size() < 4) {
+    while (pos < d.size() && std::isspace(d[pos])) ++pos;
+    if (pos < d.size() && d[pos] == '#') { while (pos < d.size() && d[pos] != '\n') ++pos; continue; }
+    size_t end = pos;
+    while (end < d.size() && !std::isspace(d[end])) ++end;
+    if (end == pos) return bad("truncated PNM header");
+    tok.emplace_back((const char*)&d[pos], end - pos);
+    pos = end;
+  }
+  ++pos;
+  if ((tok[0] != "P5" && tok[0] != "P6") || tok[3] != "255" || !IsNumber(tok[1]) || !IsNumber(tok[2])) return bad("only binary P5 / P6 with maxval 255 is read");
+  const long lw = std::atol(tok[1].c_str()), lh = std::atol(tok[2].c_str());
+  const size_t ch = tok[0] == "P6" ? 3 : 1;
+  if (lw <= 0 || lh <= 0 || (uint64_t)lw * lh > (1u << 28) || pos > d.size() || d.size() - pos < (size_t)lw * lh * ch) return bad("pixel data shorter than the header says");
+  w = (uint32_t)lw; h = (uint32_t)lh;
+  out.assign((size_t)w * h * 4, 255);
+  for (size_t i = 0; i < (size_t)w * h; ++i)
+    for (size_t k = 0; k < 3; ++k) out[i * 4 + k] = d[pos + i * ch + (ch == 3 ? k : 0)];
+  return true;
+}
+
+bool ReadImageRgba8(const std::string& aPath, std::vector<uint8_t>& out, uint32_t& w, uint32_t& h, std::string* err) {
+  std::ifstream f(aPath, std::ios::binary);
+  if (!f) { if (err) *err = "cannot open " + aPath; return false; }
+  std::vector<uint8_t> d((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+  static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', '\r', '\n', 0x1a, '\n'};
+  if (d.size() >= 8 && memcmp(d.data(), sig, 8) == 0) return ReadPng(d, aPath, out, w, h, err);
+  if (d.size() >= 2 && d[0] == 'P' && (d[1] == '5' || d[1] == '6')) return ReadPnm(d, aPath, out, w, h, err);
+  if (err) *err = aPath + ": unsupported image format (8-bit PNG and binary PPM / PGM are read)";
+  return false;
 }
 
 bool ImportObj(const std::string& aPath, SceneData& out, std::string* err) {
@@ -138,6 +272,28 @@ bool ImportObj(const std::string& aPath, SceneData& out, std::string* err) {
     inst.myMaterialIndex = mi == matOrder.end() ? 0u : (uint32_t)(mi - matOrder.begin());
     out.myMeshes.push_back(std::move(m));
     out.myInstances.push_back(inst);
+  }
+  // material extension from the MTL's PBR statements (none: the reference's material model, nothing attached)
+  bool anyExt = false;
+  for (auto& md : out.myMaterials) anyExt = anyExt || md.myHasPbr || md.myAlbedoPattern != 0 || !md.myAlbedoMap.empty();
+  if (anyExt) {
+    std::string texPath;
+    for (auto& md : out.myMaterials) {
+      PtMaterialExt e;
+      memset(&e, 0, sizeof(e));
+      e.roughness = md.myRoughness;
+      e.metallic = md.myMetallic;
+      e.albedo_pattern = md.myAlbedoPattern;
+      e.pattern_scale = md.myPatternScale;
+      e.flags = md.myHasPbr ? PT_MAT_GGX : 0u;
+      if (!md.myAlbedoMap.empty()) {
+        if (texPath.empty()) texPath = md.myAlbedoMap;
+        if (md.myAlbedoMap == texPath) { e.albedo_pattern = 3; e.pattern_scale = md.myAlbedoMapScale; }
+        else out.mySkippedTextures.push_back(md.myAlbedoMap);
+      }
+      out.myMaterialsExt.push_back(e);
+    }
+    if (!texPath.empty() && !ReadImageRgba8(texPath, out.myAlbedoTexture, out.myAlbedoWidth, out.myAlbedoHeight, err)) return false;
   }
   return true;
 }
@@ -284,6 +440,12 @@ void PathTracer::InitRtScene(const SceneData& aScene) {
   }
   Check(pt_scene_create(myCtx, meshes.data(), (uint32_t)meshes.size(), inst.data(), (uint32_t)inst.size(), mats.data(),
                         (uint32_t)mats.size(), PT_SCENE_DEFAULT));
+  if (!aScene.myMaterialsExt.empty()) {   // material extension read from the MTL (not in the reference)
+    if (aScene.myMaterialsExt.size() != aScene.myMaterials.size()) throw PtException(PT_ERR_INVALID_ARG, "one PtMaterialExt per material");
+    Check(pt_scene_set_material_ext(myCtx, aScene.myMaterialsExt.data(), (uint32_t)aScene.myMaterialsExt.size()));
+    if (!aScene.myAlbedoTexture.empty())
+      Check(pt_scene_set_albedo_texture(myCtx, aScene.myAlbedoTexture.data(), aScene.myAlbedoWidth, aScene.myAlbedoHeight));
+  }
 }
 
 void PathTracer::UpdateOutputTexture() {

@@ -29,12 +29,30 @@ struct SceneMeshInstance {
 struct MaterialDesc {
   float myEmission[3] = {0, 0, 0};
   float myColor[4] = {1, 1, 1, 1};
+  // material extension as read from MTL (not in the reference): Pr / Pm select the GGX model, map_Kd [-s u v w] names the
+  // albedo image, pt_albedo_pattern <id> <scale> a procedural pattern
+  bool myHasPbr = false;
+  float myRoughness = 0.5f, myMetallic = 0.0f;
+  uint32_t myAlbedoPattern = 0;
+  float myPatternScale = 1.0f;
+  std::string myAlbedoMap;                 // path of the map_Kd file ("" = none)
+  float myAlbedoMapScale = 1.0f;
 };
 struct SceneData {
   std::vector<MeshData> myMeshes;
   std::vector<SceneMeshInstance> myInstances;
   std::vector<MaterialDesc> myMaterials;
+  // filled by ImportObj when the MTL carries PBR statements; InitRtScene hands them to pt_scene_set_material_ext /
+  // pt_scene_set_albedo_texture (one image per scene: the first map_Kd file; materials naming another keep their Kd)
+  std::vector<PtMaterialExt> myMaterialsExt;
+  std::vector<uint8_t> myAlbedoTexture;    // RGBA8, row 0 = top
+  uint32_t myAlbedoWidth = 0, myAlbedoHeight = 0;
+  std::vector<std::string> mySkippedTextures;
 };
+
+// Texture file -> RGBA8 texels: 8-bit non-interlaced PNG (every colour type, all row filters) and binary PPM / PGM.
+bool ReadImageRgba8(const std::string& aPath, std::vector<uint8_t>& someTexelsOut, uint32_t& aWidthOut, uint32_t& aHeightOut,
+                    std::string* anErrorOut = nullptr);
 
 // Minimal OBJ/MTL import: one mesh + instance per (o/g, usemtl) run in file order (stand-in for MeshImporter::Import).
 bool ImportObj(const std::string& aPath, SceneData& aSceneOut, std::string* anErrorOut = nullptr);

@@ -19,6 +19,18 @@ int main(int argc, char** argv) {
     size_t tris = 0;
     for (const auto& m : sd.myMeshes) tris += m.myIndexData.size() / 3;
     printf("meshes %zu triangles %zu materials %zu\n", sd.myMeshes.size(), tris, sd.myMaterials.size());
+    for (size_t i = 0; i < sd.myMaterialsExt.size(); ++i) {   // material extension read from the MTL, one line per material
+      const PtMaterialExt& e = sd.myMaterialsExt[i];
+      printf("ext %zu roughness %.9g metallic %.9g pattern %u scale %.9g flags %u\n", i, e.roughness, e.metallic, e.albedo_pattern,
+             e.pattern_scale, e.flags);
+    }
+    if (!sd.myAlbedoTexture.empty()) {
+      uint32_t sum = 0;   // Adler-style checksum of the texels, for comparison with the Python host's decoder
+      uint32_t a = 1, b = 0;
+      for (uint8_t t : sd.myAlbedoTexture) { a = (a + t) % 65521u; b = (b + a) % 65521u; }
+      sum = (b << 16) | a;
+      printf("texture %ux%u adler32 %u skipped %zu\n", sd.myAlbedoWidth, sd.myAlbedoHeight, sum, sd.mySkippedTextures.size());
+    }
     return 0;
   }
   if (argc < 3) {

@@ -1758,3 +1758,22 @@ def test_textured_obj_file_renders_like_the_scene_it_was_written_from(ctx, oracl
     lut = oracle.transmittance_lut(oracle.earth_atmosphere())
     ref, _, _ = oracle.scene(back).render(c, w, h, 0, spp, lut=lut)
     assert rel_mse(imgs[1][..., :3] / spp, ref[..., :3] / spp) < 1e-4
+    # the C++ host (own MTL / PNG readers) renders the file to the same bits as the Python host
+    import subprocess
+    from pathtracer_amd import PathTracer
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cli = os.path.join(root, "host", "pt_render_cli")
+    out = str(tmp_path / "tex.pfm")
+    r = subprocess.run([cli, obj, out, "--spp", "4", "--width", "160", "--height", "96", "--cam", "3", "3", "-7", "--depth", "3",
+                        "--light-instance", "5"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    from pathtracer_amd.image_io import read_pfm
+    img = read_pfm(out)
+    pt = PathTracer(0, 160, 96)
+    pt.LoadScene(obj, (3.0, 3.0, -7.0))
+    pt.myMaxRecursionDepth = 3
+    pt.myLightInstanceIdx = 5
+    pt.RenderRT(4)
+    mine = pt.ReadOutput()
+    pt.ctx.close()
+    assert img.shape == mine[..., :3].shape and np.array_equal(img, mine[..., :3]) and img.max() > 0

@@ -238,6 +238,29 @@ def test_textured_obj_mtl_roundtrip(tmp_path):
     assert hs.materials_ext == [(0.25, 0.0, 3, 4.0, api.PT_MAT_GGX), (0.5, 0.0, 0, 1.0, 0), (0.5, 1.0, 0, 1.0, api.PT_MAT_GGX)]
     assert hs.albedo_texture.shape == (4, 6, 4) and np.array_equal(hs.albedo_texture[..., :3], tex)
     assert len(hs.skipped_textures) == 1 and hs.skipped_textures[0].endswith("other.png")
+    # the C++ host's importer (host/PathTracerHost.cpp: own MTL parser, PNG / PPM decoders over zlib) reads the same files alike
+    import subprocess
+    import zlib
+    cli = os.path.join(ROOT, "host", "pt_render_cli")
+    assert os.path.exists(cli), "build host/pt_render_cli first (__graft_entry__.build())"
+    for path, want in ((obj, back), (str(tmp_path / "h.obj"), hs)):
+        r = subprocess.run([cli, "--check-obj", path], capture_output=True, text=True, timeout=60)
+        assert r.returncode == 0, r.stderr
+        rows = [ln.split() for ln in r.stdout.splitlines() if ln.startswith("ext ")]
+        assert len(rows) == len(want.materials_ext)
+        for row, (rough, metal, pattern, scale, flags) in zip(rows, want.materials_ext):
+            assert (int(row[7]), int(row[11])) == (pattern, flags) and np.float32(row[9]) == np.float32(scale)
+            assert np.float32(row[3]) == np.float32(rough) and np.float32(row[5]) == np.float32(metal)
+        tex = [ln.split() for ln in r.stdout.splitlines() if ln.startswith("texture ")][0]
+        th, tw = want.albedo_texture.shape[:2]
+        assert tex[1] == f"{tw}x{th}" and int(tex[3]) == zlib.adler32(want.albedo_texture.tobytes())
+        assert int(tex[5]) == len(getattr(want, "skipped_textures", []))
+    (tmp_path / "bad.mtl").write_text("newmtl a\nmap_Kd missing.png\n")
+    (tmp_path / "bad.obj").write_text("mtllib bad.mtl\nv 0 0 0\nv 1 0 0\nv 0 1 0\nusemtl a\nf 1 2 3\n")
+    r = subprocess.run([cli, "--check-obj", str(tmp_path / "bad.obj")], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 1 and "missing.png" in r.stderr
+    with pytest.raises(OSError):
+        scenes.load_obj(str(tmp_path / "bad.obj"))
     (tmp_path / "n.mtl").write_text("newmtl a\nKd 1 1 1\n")
     (tmp_path / "n.obj").write_text("mtllib n.mtl\nv 0 0 0\nv 1 0 0\nv 0 1 0\nusemtl a\nf 1 2 3\n")
     assert scenes.load_obj(str(tmp_path / "n.obj")).materials_ext is None     # no PBR statement: the reference's material model
