@@ -787,6 +787,41 @@ def test_frame_lanes_overlap_small_frames_with_identical_bits(ctx, oracle):
         ctx.set_option(api.PT_OPT_FRAME_LANES, 9)
 
 
+def test_rccl_backend_runs_the_collectives_the_multi_gpu_path_uses():
+    """The box has one GPU, so RCCL never sees a second rank here; what CAN be checked is that every collective the N > 1
+    path issues (bench.py, pathtracer_amd/distributed.py) is accepted by the nccl (= RCCL) backend on this device with the
+    dtypes and shapes used: eager init with device_id, reduce of a W*H*4 float target, gather of block sums, int64 SUM and
+    float64 MAX / SUM all-reduces, barrier. One rank, in a process of its own (a process group must not leak into pytest)."""
+    import subprocess
+    import sys
+    code = r"""
+import os, socket, torch, torch.distributed as dist
+s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+torch.cuda.set_device(0)
+dist.init_process_group(backend="nccl", device_id=torch.device("cuda", 0))
+dev = torch.device("cuda", 0)
+t = torch.full((1920 * 1080 * 4,), 0.5, dtype=torch.float32, device=dev)
+dist.reduce(t, dst=0, op=dist.ReduceOp.SUM)
+blocks = torch.arange(8 * 1024, dtype=torch.float32, device=dev).reshape(8, 1024)
+parts = [torch.empty_like(blocks)]
+dist.gather(blocks, gather_list=parts, dst=0)
+cnt = torch.tensor([4096], dtype=torch.int64, device=dev)
+dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
+ms = torch.tensor([1.25], dtype=torch.float64, device=dev)
+dist.all_reduce(ms, op=dist.ReduceOp.MAX)
+dist.all_reduce(ms, op=dist.ReduceOp.SUM)
+dist.barrier()
+torch.cuda.synchronize()
+assert float(t[0]) == 0.5 and torch.equal(parts[0], blocks) and int(cnt) == 4096 and float(ms) == 1.25
+dist.destroy_process_group()
+print("rccl ok")
+"""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=240, env=env)
+    assert r.returncode == 0 and "rccl ok" in r.stdout, r.stderr[-2000:]
+
+
 # ---------------------------------------------------------------------------------------------- bench launcher
 def test_bench_gpus_2_starts_two_ranks_by_itself():
     """`python bench.py --gpus 2` (the driver's form) must run TWO ranks: rehearsed on this one-GPU box with gloo and
