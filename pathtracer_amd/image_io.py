@@ -104,32 +104,35 @@ def read_png(path):
         raise ValueError(f"{path}: {len(raw)} bytes of image data, expected {h * (stride + 1)}")
     rows = np.frombuffer(raw, dtype=np.uint8).reshape(h, stride + 1)
     out = np.zeros((h, stride), dtype=np.uint8)
-    prev = np.zeros(stride, dtype=np.int32)
+    prev = bytes(stride)
     for y in range(h):
-        ft, line = int(rows[y, 0]), rows[y, 1:].astype(np.int32)
+        ft, line = int(rows[y, 0]), rows[y, 1:]
         if ft == 0:
-            cur = line
+            cur = line.tobytes()
         elif ft == 2:                                      # Up
-            cur = (line + prev) & 255
-        elif ft in (1, 3, 4):                              # Sub, Average, Paeth: depend on the pixel to the left
-            cur = np.zeros(stride, dtype=np.int32)
-            lp, pp = line.reshape(w, bpp), prev.reshape(w, bpp)
-            cp = cur.reshape(w, bpp)
-            left, upleft = np.zeros(bpp, dtype=np.int32), np.zeros(bpp, dtype=np.int32)
-            for x in range(w):
-                up = pp[x]
-                if ft == 1:
-                    pred = left
-                elif ft == 3:
-                    pred = (left + up) >> 1
-                else:
-                    pa, pb, pc = np.abs(up - upleft), np.abs(left - upleft), np.abs(left + up - 2 * upleft)
-                    pred = np.where((pa <= pb) & (pa <= pc), left, np.where(pb <= pc, up, upleft))
-                cp[x] = (lp[x] + pred) & 255
-                left, upleft = cp[x], up
+            cur = (line + np.frombuffer(prev, dtype=np.uint8)).tobytes()            # uint8 addition wraps mod 256
+        elif ft == 1:                                      # Sub: a running sum along the row, per channel, mod 256
+            cur = np.cumsum(line.reshape(w, bpp), axis=0, dtype=np.uint32).astype(np.uint8).tobytes()
+        elif ft in (3, 4):                                 # Average, Paeth: sequential in x — a plain byte loop
+            src, c = line.tobytes(), bytearray(stride)
+            if ft == 3:
+                for i in range(stride):
+                    a = c[i - bpp] if i >= bpp else 0
+                    c[i] = (src[i] + ((a + prev[i]) >> 1)) & 255
+            else:
+                for i in range(stride):
+                    if i >= bpp:
+                        a, b, d = c[i - bpp], prev[i], prev[i - bpp]
+                        p0 = a + b - d
+                        pa, pb, pc = abs(p0 - a), abs(p0 - b), abs(p0 - d)
+                        pred = a if (pa <= pb and pa <= pc) else (b if pb <= pc else d)
+                    else:
+                        pred = prev[i]
+                    c[i] = (src[i] + pred) & 255
+            cur = bytes(c)
         else:
             raise ValueError(f"{path}: row {y} has filter type {ft}")
-        out[y] = cur
+        out[y] = np.frombuffer(cur, dtype=np.uint8)
         prev = cur
     px = out.reshape(h, w, channels)
     img = np.full((h, w, 4), 255, dtype=np.uint8)
