@@ -77,6 +77,23 @@ def make_workload(name):
         return scenes.courtyard(3), scenes.COURTYARD_CAM, 16, "C5 courtyard(seed=3) 10485760 tris, sky on"
     if name == "cornell":
         return scenes.cornell_box(), None, 4, "C1 Cornell box 36 tris, sky off"
+    if name.startswith("obj:"):
+        # "if $PT_SCENE_DIR/sponza.obj exists on the box, also run it" — any OBJ/MTL file through the Python host's
+        # reader (scenes.load_obj). The camera is placed from the bounding box: a sixth of the height above the floor at the
+        # centre, looking down the longer horizontal axis (the view the atrium stand-in uses for its own courtyard).
+        import numpy as np
+        path = name[4:]
+        scene = scenes.load_obj(path)
+        pts = np.concatenate([scene.meshes[m][0]["pos"] for m, _, _ in scene.instances])
+        lo, hi = pts.min(axis=0).astype(np.float64), pts.max(axis=0).astype(np.float64)
+        c, ext = 0.5 * (lo + hi), hi - lo
+        eye = np.array([c[0], lo[1] + ext[1] / 6.0, c[2]])
+        axis = 0 if ext[0] >= ext[2] else 2
+        eye[axis] = c[axis] - 0.35 * ext[axis]
+        target = eye.copy()
+        target[axis] = c[axis] + 0.5 * ext[axis]
+        cam = {"eye": tuple(float(x) for x in eye), "target": tuple(float(x) for x in target)}
+        return scene, cam, 4, f"OBJ file {os.path.basename(path)} {scene.num_triangles} tris, sky on"
     raise ValueError(name)
 
 
@@ -337,7 +354,8 @@ def main():
     ap.add_argument("--spp-per-step", type=int, default=64,
                     help="samples per pixel rendered by one step (one pt_render call = one wavefront batch)")
     ap.add_argument("--depth", type=int, default=-1, help="myMaxRecursionDepth (default: the workload's)")
-    ap.add_argument("--workload", default="atrium", choices=list(WORKLOADS))
+    ap.add_argument("--workload", default="atrium", choices=list(WORKLOADS) + ["obj"])
+    ap.add_argument("--scene-obj", default="", help="--workload obj: the OBJ/MTL file to render (default: $PT_SCENE_DIR/sponza.obj)")
     ap.add_argument("--sky-mode", type=int, default=0, choices=[0, 1],
                     help="0 = ray-march the sky on every miss (reference semantics); 1 = direction LUT (relMSE ~1e-6)")
     ap.add_argument("--material-ext", type=int, default=0, choices=[0, 1],
@@ -363,7 +381,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="skip the short legs of the other BASELINE configurations (\"configs\" in the JSON line)")
-    ap.add_argument("--configs", default="", help="comma-separated subset of the legs to run: " + ",".join(k for k, _ in CONFIG_LEGS))
+    ap.add_argument("--configs", default="", help="comma-separated subset of the legs to run: " + ",".join(k for k, _ in CONFIG_LEGS) +
+                    " (and C2_sponza_obj when $PT_SCENE_DIR/sponza.obj or --scene-obj names a file)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
     ap.add_argument("--all-ranks-on-gpu0", action="store_true", help="rehearsal: every rank uses cuda:0")
     args = ap.parse_args()
@@ -404,6 +423,12 @@ def main():
     torch.cuda.set_device(dev)
 
     W, H, K, WU, SPP = args.width, args.height, args.steps, args.warmup, args.spp_per_step
+    obj_path = args.scene_obj or (os.path.join(os.environ["PT_SCENE_DIR"], "sponza.obj") if os.environ.get("PT_SCENE_DIR") else "")
+    if args.workload == "obj":
+        if not os.path.isfile(obj_path):
+            print(f"bench.py: --workload obj needs --scene-obj FILE or $PT_SCENE_DIR/sponza.obj ({obj_path!r} is not a file)", file=sys.stderr)
+            sys.exit(2)
+        args.workload = "obj:" + obj_path
     pt = PathTracer(local_rank, W, H)
     pt.myHalfResRender = False
     pt.UpdateOutputTexture()
@@ -536,13 +561,16 @@ def main():
     default_cmd = (args.workload == "atrium" and (W, H) == (1920, 1080) and not args.material_ext and not args.russian_roulette
                    and args.depth < 0 and not args.bit_identical)
     if rank == 0 and world == 1 and not args.no_configs and not args.no_roofline and (default_cmd or args.configs):
-        want = [k for k in args.configs.split(",") if k] or [k for k, _ in CONFIG_LEGS]
+        legs = list(CONFIG_LEGS)
+        if os.path.isfile(obj_path):   # a real asset on the box ($PT_SCENE_DIR/sponza.obj or --scene-obj) runs beside the stand-ins
+            legs.append(("C2_sponza_obj", {"workload": "obj:" + obj_path, "width": 1920, "height": 1080, "spp_per_step": 64, "steps": 2}))
+        want = [k for k in args.configs.split(",") if k] or [k for k, _ in legs]
         configs = {}
         ctx.set_option(api.PT_OPT_SKY_MODE, 0)
         ctx.set_option(api.PT_OPT_PIPELINE, 0)
         ctx.synchronize()
         del target
-        for key, spec in CONFIG_LEGS:
+        for key, spec in legs:
             if key not in want:
                 continue
             try:

@@ -823,6 +823,33 @@ print("rccl ok")
 
 
 # ---------------------------------------------------------------------------------------------- bench launcher
+def test_bench_runs_an_obj_file_and_the_optional_sponza_leg(tmp_path):
+    """'if $PT_SCENE_DIR/sponza.obj exists on the box, also run it'. bench.py --workload obj renders any OBJ/MTL
+    file through the host's reader with a camera placed from the bounding box, and the default line gains a C2_sponza_obj leg
+    when the file exists (rehearsed with a small stand-in file under that name; the real asset is not available offline)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sc = scenes.random_triangle_soup(5, 4000, extent=12.0, size=1.5)
+    scenes.scene_to_obj(sc, str(tmp_path / "sponza.obj"))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "PT_SCENE_DIR")}
+    small = ["--steps", "1", "--warmup", "1", "--width", "320", "--height", "180", "--spp-per-step", "2", "--no-cpu-baseline"]
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--workload", "obj", "--scene-obj", str(tmp_path / "sponza.obj"),
+                        "--no-configs"] + small, capture_output=True, text=True, timeout=300, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["config"]["triangles"] == 4000 and "sponza.obj" in d["config"]["workload"] and d["value"] > 0
+    assert d["roofline"]["nodes_per_ray"] > 1.0 and d["config"]["rays_per_sample"] > 1.05     # the camera sees geometry
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--workload", "obj", "--no-configs"] + small,
+                       capture_output=True, text=True, timeout=120, env=env, cwd=root)
+    assert r.returncode == 2 and "sponza.obj" in r.stderr                                       # no file named: an error, not a default scene
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--workload", "cornell", "--configs", "C2_sponza_obj"] + small,
+                       capture_output=True, text=True, timeout=300, env=dict(env, PT_SCENE_DIR=str(tmp_path)), cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    leg = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])["configs"]["C2_sponza_obj"]
+    assert "error" not in leg and leg["triangles"] == 4000 and leg["mrays_per_s"] > 0 and (leg["width"], leg["height"]) == (1920, 1080)
+
+
 def test_bench_gpus_2_starts_two_ranks_by_itself():
     """`python bench.py --gpus 2` (the driver's form) must run TWO ranks: rehearsed on this one-GPU box with gloo and
     both ranks on cuda:0. A --gpus value that disagrees with WORLD_SIZE is an error, not a silent 1-GPU run."""
