@@ -96,4 +96,14 @@ for on in (0, 1):
 orc.set_russian_roulette(0)
 json.dump(rr, open(os.path.join(G, "cornell_rr_64_8spp_stats.json"), "w"), indent=1)
 
+# ---- path probe (ClosestHit / payload rows a7-a9): the rays every path of sample 3 carries into bounces 1 and 2, Cornell 64^2 ----
+c = cornell_consts(64, 64)
+probe = {}
+for b in (1, 2):
+    r, alive, state = osc.bounce_rays(c, 64, 64, 3, b)
+    probe[f"alive_{b}"] = np.packbits(alive)
+    probe[f"rays_{b}"] = r[alive]
+    probe[f"state_{b}"] = state[alive]
+np.savez_compressed(os.path.join(G, "cornell_bounce_rays_64.npz"), **probe)
+
 print("golden fixtures written to", G, sorted(os.listdir(G)))

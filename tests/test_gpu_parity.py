@@ -1594,6 +1594,26 @@ def test_bounce_queues_match_the_oracle_path_probe(ctx, oracle, scene_name):
         assert len(np.unique(idx[ok])) == int(ok.sum())   # one to one
 
 
+def test_bounce_queue_matches_the_committed_fixture(ctx):
+    """The same check against data instead of the live oracle: tests/golden/cornell_bounce_rays_64.npz (written by
+    make_golden.py from the oracle) holds the rays the paths of sample 3 carry into bounce 1 of the Cornell box at 64x64;
+    k_shade's bounce-1 queue has exactly those origins (bit for bit) and directions within the shading tolerance."""
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "cornell_bounce_rays_64.npz"))
+    want = g["rays_1"]
+    ctx.scene_create(scenes.cornell_box())
+    c = cornell_consts(64, 64)
+    c.myMaxRecursionDepth = 1
+    ctx.accum_reset(64, 64)
+    ctx.render(c, 64, 64, 3, 1)
+    q = ctx.debug_read_queue(1)
+    assert len(q) == len(want) == int(np.unpackbits(g["alive_1"]).sum())
+    ko = np.lexsort(want["origin"].view(np.uint32).T[::-1])
+    kq = np.lexsort(q["origin"].view(np.uint32).T[::-1])
+    assert np.array_equal(q["origin"][kq].view(np.uint32), want["origin"][ko].view(np.uint32))
+    assert np.abs(q["dir"][kq] - want["dir"][ko]).max() < 2e-4
+    assert (q["tmin"] == np.float32(0.001)).all() and (q["tmax"] == np.float32(10000.0)).all()
+
+
 # ---------------------------------------------------------------------------------------------- API behaviour
 def test_default_batch_shrinks_when_device_memory_is_short():
     """The default wavefront batch is 2^27 paths (20 GB). When that much device memory is not free, pt_render halves the

@@ -180,6 +180,24 @@ def test_bounce_ray_probe_is_consistent_with_the_render(oracle):
     assert total == st["rays"]
 
 
+def test_bounce_ray_probe_pinned(oracle):
+    """Regression pin of the path probe (tests/golden/make_golden.py): which paths of sample 3 reach bounces 1 and 2 of the
+    Cornell box at 64x64 (exact), their origins (bit-exact: fp32 multiply-add of pinned primaries and hit distances), their
+    directions and the transmission / luminance carried so far (libm-dependent: 2e-6)."""
+    g = np.load(os.path.join(G, "cornell_bounce_rays_64.npz"))
+    osc = oracle.scene(scenes.cornell_box())
+    c = cornell_consts(64, 64)
+    for b in (1, 2):
+        r, alive, state = osc.bounce_rays(c, 64, 64, 3, b)
+        assert np.array_equal(np.packbits(alive), g[f"alive_{b}"])
+        want = g[f"rays_{b}"]
+        if b == 1:
+            assert np.array_equal(r[alive]["origin"].view(np.uint32), want["origin"].view(np.uint32))
+        np.testing.assert_allclose(r[alive]["origin"], want["origin"], rtol=2e-6, atol=1e-5)
+        np.testing.assert_allclose(r[alive]["dir"], want["dir"], rtol=0, atol=2e-6)
+        np.testing.assert_allclose(state[alive], g[f"state_{b}"], rtol=2e-5, atol=1e-7)
+
+
 def test_running_mean_equals_sum_over_n(oracle):
     """The reference's running mean (PathTracing.hlsl:134-137) vs the product's sum target: same image."""
     osc = oracle.scene(scenes.cornell_box())
